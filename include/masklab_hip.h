@@ -1,0 +1,170 @@
+/*
+ * masklab_hip.h -- C ABI of libmasklab_hip.so (gfx950 / MI355X).
+ *
+ * The reference (craftsangjae/instance-segmentation-road-project) is pure Python on
+ * tensorflow.keras and has NO FFI of its own: every arithmetic step of
+ * its inference path is a TensorFlow op.  Each entry point below therefore replaces
+ * the TF op(s) behind the cited reference call site (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (the library never
+ *     allocates persistent memory; scratch is a caller-provided workspace);
+ *   - tensors are NHWC float32 unless stated; "cstride" = channels of the buffer a
+ *     tensor view lives in, "coff" = first channel of the view (lets a kernel read or
+ *     write a slice of a concat buffer without a copy);
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work;
+ *   - return value: 0 = ok, negative = ML_E_* (no exceptions cross the boundary);
+ *   - thread-safe per stream, no global mutable state besides the error string.
+ */
+#ifndef MASKLAB_HIP_H
+#define MASKLAB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ML_OK 0
+#define ML_E_BADARG (-1)   /* shape / alignment / range precondition violated */
+#define ML_E_LAUNCH (-2)   /* hipLaunchKernel or attribute call failed        */
+#define ML_E_NOGPU  (-3)   /* no gfx950 device visible                        */
+
+enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
+
+int ml_version(void);                 /* ABI version, currently 1                         */
+const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
+int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
+
+/* ---------------------------------------------------------------- convolution (MFMA)
+ * Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32: M = B*Ho*Wo output pixels,
+ * N = cout, K = taps * span_pad.  Replaces tf.keras Conv2D (+folded BatchNormalization,
+ * +Add, +activation), the ResNeXt grouped 3x3 and Conv2DTranspose(2,2,s2):
+ *   engine/backbone/ResNext.py:200-231,343-349   engine/backbone/base.py:294-312
+ *   engine/layers/detection.py:42-48,56,64,120-128,190-200
+ *   engine/layers/instance.py:188-199            engine/layers/semantic.py:66,112,126,133,199,213,219
+ * Weights are pre-packed by the host as wgt[n_pad][taps*span_pad] (k contiguous,
+ * k = tap*span_pad + c, zero padded; see masklab_hip/packing.py).
+ */
+typedef struct ml_conv2d_desc {
+    const float *in;        /* [B,H,W,in_cstride] view starting at channel in_coff            */
+    const float *wgt;       /* packed weights, n_pad rows of ktot floats                      */
+    const float *bias;      /* [cout] or NULL                                                 */
+    const float *residual;  /* optional tensor added before the activation, or NULL          */
+    float *out;             /* [B,Ho,Wo,out_cstride] view starting at channel out_coff        */
+    int32_t B, H, W;        /* input batch / height / width                                   */
+    int32_t in_cstride, in_coff;
+    int32_t span;           /* K floats per tap actually read (cin; 32 for the NHWC4 stem)    */
+    int32_t span_pad;       /* span rounded up to 32                                          */
+    int32_t cpp_shift;      /* stem: log2(floats per pixel) so a tap spans pixels; else 30    */
+    int32_t Ho, Wo;
+    int32_t KH, KW, stride, dil, pad_t, pad_l;
+    int32_t cout;           /* real N                                                         */
+    int32_t n_pad;          /* rows in wgt (multiple of the N tile)                           */
+    int32_t out_cstride, out_coff;
+    int32_t res_cstride, res_coff;
+    int32_t act;            /* ML_ACT_*                                                       */
+    int32_t group_cin_step; /* grouped 3x3: input-channel offset per 32-wide N block; else 0  */
+    int32_t shuffle2x2;     /* 1: Conv2DTranspose epilogue, column = (a*2+b)*cout_real + o    */
+    int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32                    */
+    int64_t out_bstride;    /* floats between images in `out`; 0 = Ho*Wo*out_cstride (dense).
+                               Lets a level's head write straight into the concatenated
+                               [B, A, classes] prediction (detection.py:210-212 Reshape+Concatenate) */
+} ml_conv2d_desc;
+
+int ml_conv2d_f32(const ml_conv2d_desc *d, void *stream);
+/* N-tile width the auto heuristic picks for `cout` (host packs n_pad from it). */
+int ml_conv2d_ntile(int32_t cout, int32_t tile);
+
+/* ---------------------------------------------------------------- depthwise / pooling
+ * 3x3 DepthwiseConv2D (depth_multiplier 1), stride 1/2, dilation, explicit pads, +bias
+ * (folded BN) +activation.  tf.keras.applications MobileNet body; semantic.py:63; misc.py:85.
+ * wgt is [9][C] (tap major).                                                              */
+int ml_dwconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out,
+                     int32_t B, int32_t H, int32_t W, int32_t C,
+                     int32_t in_cstride, int32_t in_coff, int32_t out_cstride, int32_t out_coff,
+                     int32_t Ho, int32_t Wo, int32_t stride, int32_t dil,
+                     int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
+
+/* ZeroPadding2D(1)+MaxPooling2D(3,2) on a non-negative (post-ReLU) map: ResNext.py:351-352 */
+int ml_maxpool3x3s2_f32(const float *in, float *out, int32_t B, int32_t H, int32_t W, int32_t C,
+                        int32_t Ho, int32_t Wo, int32_t pad_t, int32_t pad_l, void *stream);
+
+/* BackBonePreProcess (engine/backbone/base.py:57-75) fused with the NHWC->NHWC4 repack the
+ * MFMA stem wants: out[...,k] = (in[..., flip?2-k:k] - mean[k]) * scale + shift, out[...,3]=0.
+ * in is uint8 (is_u8=1) or float32 RGB [B,H,W,3]; out_c is 3 or 4.                          */
+int ml_preprocess_f32(const void *in, int32_t is_u8, float *out, int64_t npix, int32_t out_c,
+                      int32_t flip, float mean0, float mean1, float mean2,
+                      float scale, float shift, void *stream);
+
+/* ---------------------------------------------------------------- GroupNormalization
+ * The reference's chunk-wise GroupNormalization (engine/normalization.py:116-160):
+ * per sample, the flat H*W*C vector is cut into G contiguous chunks; y=(x-mean_g)/sqrt(var_g+eps)
+ * * gamma[j] + beta[j], j = g*(C/G) + (c mod C/G).  Optional fused ReLU (semantic.py:72-73,
+ * 116,137,202).  workspace: >= ml_groupnorm_workspace_bytes() bytes.  In-place (y==x) allowed. */
+int64_t ml_groupnorm_workspace_bytes(int32_t N, int32_t G);
+int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const float *beta,
+                           int32_t N, int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu,
+                           int32_t out_cstride, int32_t out_coff, /* y view: channels of the buffer / first channel; (C,0) = dense */
+                           void *workspace, void *stream);
+
+/* ---------------------------------------------------------------- resampling / reductions
+ * tf.compat.v1.image.resize_bilinear(align_corners=True) (engine/layers/misc.py:306), with the
+ * FPN `Add` (detection.py:58-60) or a concat-slice write (semantic.py:154,227) fused.        */
+int ml_resize_bilinear_ac_f32(const float *in, const float *add, float *out,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                              int32_t Ho, int32_t Wo, int32_t add_cstride, int32_t add_coff,
+                              int32_t out_cstride, int32_t out_coff, void *stream);
+
+/* tf.reduce_mean over H,W (semantic.py:149; GlobalAveragePooling2D misc.py:43): [B,HW,C]->[B,C] */
+int ml_global_mean_f32(const float *in, float *out, int32_t B, int32_t HW, int32_t C, void *stream);
+
+/* x[b,h,w,c] *= s[b,c]  (SqueezeExcite scale, misc.py:46-47)                                 */
+int ml_scale_channels_f32(float *x, const float *s, int32_t B, int32_t HW, int32_t C, void *stream);
+
+/* ---------------------------------------------------------------- detection post-process
+ * RestoreBoxes (engine/layers/detection.py:325-344): priors int32 [A,4] (cx,cy,w,h) shared by
+ * the batch; loc [B,A,4] -> boxes [B,A,4].                                                    */
+int ml_restore_boxes_f32(const float *loc, const int32_t *priors, float *boxes,
+                         int32_t B, int32_t A, void *stream);
+
+/* DetectionProposal (detection.py:482-567) in fixed capacity: threshold -> per-(image,class)
+ * greedy NMS -> per-image cross-class NMS -> rows (cx,cy,w,h,class,conf), -1 padded.
+ *   cls_pred [B,A,C], boxes [B,A,4] -> proposed [B,max_out,6], counts [B] (int32),
+ *   kept [B,max_out,2] (anchor, class) int32 or NULL.
+ * workspace: >= ml_detection_workspace_bytes(B,A,C,max_out) bytes.                            */
+int64_t ml_detection_workspace_bytes(int32_t B, int32_t A, int32_t C, int32_t max_out);
+int ml_detection_proposal_f32(const float *cls_pred, const float *boxes, float *proposed,
+                              int32_t *counts, int32_t *kept, int32_t B, int32_t A, int32_t C,
+                              float min_confidence, float nms_iou, float post_iou, int32_t max_out,
+                              void *workspace, void *stream);
+
+/* MaskDistribute (engine/layers/instance.py:52-66) + the per-level `tf.where` of
+ * PyramidRoiAlign (instance.py:121): proposed [B,cap,6] -> level_slots [B,L,cap] (row indices,
+ * ascending), level_counts [B,L].  L = max_k+1.                                                */
+int ml_mask_distribute_i32(const float *rows, int32_t row_stride, int32_t has_k,
+                           float *kvals /* [B,cap] or NULL */, int32_t *level_slots,
+                           int32_t *level_counts, int32_t B, int32_t cap, int32_t max_k,
+                           float base_size, void *stream);
+/* rows: [B,cap,row_stride]; has_k=0: rows are (cx,cy,w,h,cls,conf) and k is computed
+ * (MaskDistribute); has_k=1: rows are dist_boxes (k,cx,cy,w,h,cls,conf) and k is read.        */
+
+/* tf.image.crop_and_resize + MoldBatch(-1) for one pyramid level (instance.py:115-134):
+ * fmap [B,Hf,Wf,C]; rows [B,cap,row_stride] with (cx,cy,w,h,cls,conf) starting at column row_off;
+ * writes roi_fmaps [B,n_l,ch,cw,C] and roi_boxes[b, box_off+j, 0..5]
+ * (row stride box_rows*6); slots j >= level_counts[b,level] are filled with -1.              */
+int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int32_t row_stride, int32_t row_off,
+                           const int32_t *level_slots,
+                           const int32_t *level_counts, float *roi_fmaps, float *roi_boxes,
+                           int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
+                           int32_t level, int32_t n_l, int32_t ch, int32_t cw,
+                           float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);
+
+/* fill n floats with v */
+int ml_fill_f32(float *x, float v, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKLAB_HIP_H */

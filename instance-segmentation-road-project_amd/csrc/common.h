@@ -1,0 +1,37 @@
+// Shared helpers for the gfx950 kernels of libmasklab_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "masklab_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void ml_set_error(const char *fmt, ...);
+
+#define ML_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ml_set_error(__VA_ARGS__);        \
+            return ML_E_BADARG;               \
+        }                                     \
+    } while (0)
+
+#define ML_CHECK_LAUNCH(what)                                                     \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            ml_set_error("%s: launch failed: %s", what, hipGetErrorString(e_));   \
+            return ML_E_LAUNCH;                                                   \
+        }                                                                         \
+    } while (0)
+
+__device__ __forceinline__ float ml_apply_act(float v, int act) {
+    if (act == ML_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ML_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    if (act == ML_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+static inline bool ml_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,160 @@
+// The reference's chunk-wise GroupNormalization (engine/normalization.py:116-160).
+// Sample n's flat H*W*C vector is cut into G contiguous chunks of L = HWC/G floats;
+//   y = (x - mean_g) / sqrt(var_g + eps) * gamma[j] + beta[j],  j = g*(C/G) + (c mod C/G).
+// HBM-bound: algorithmic traffic = 1 read + 1 write of x (8 B/elt); this implementation reads x
+// twice (stats pass + apply pass) = 12 B/elt, the second read usually served by L2/Infinity Cache.
+//   pass 1: grid (S, N*G): each block sums a slice of one chunk in fp64 (sum, sum of squares)
+//           -> workspace[(n*G+g)*S + s]   (fp64 partials: no cancellation issue in E[x^2]-mean^2)
+//   pass 2: grid (S2, N*G): each block folds the S partials, then normalises its slice.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_TPB = 256;
+constexpr int GN_MAX_SPLIT = 64;
+
+struct GnPlan { int S; long long slice; };
+
+// slices are multiples of 4*GN_TPB floats so every block runs whole float4 sweeps
+static GnPlan gn_plan(long long L, int NG) {
+    long long want = (2048 + NG - 1) / NG;            // aim at >= 2048 blocks on the chip
+    if (want < 1) want = 1;
+    if (want > GN_MAX_SPLIT) want = GN_MAX_SPLIT;
+    const long long unit = 4 * GN_TPB;
+    long long slice = ((L + want - 1) / want + unit - 1) / unit * unit;
+    int S = (int)((L + slice - 1) / slice);
+    return {S, slice};
+}
+
+template <bool VEC4>
+__global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, long long L, long long slice,
+                                int S) {
+    const int ng = blockIdx.y;
+    const int s = blockIdx.x;
+    const float *p = x + (long long)ng * L;
+    const long long lo = (long long)s * slice;
+    const long long hi = min(lo + slice, L);
+    double sum = 0.0, sq = 0.0;
+    if (VEC4) {
+        for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = v[e]; sum += d; sq += d * d; }
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) { const double d = p[i]; sum += d; sq += d * d; }
+    }
+    // wave reduce (64 lanes) then across the 4 waves
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off, 64);
+        sq += __shfl_down(sq, off, 64);
+    }
+    __shared__ double red[2][GN_TPB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sum; red[1][wave] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int w = 0; w < GN_TPB / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+        ws[((long long)ng * S + s) * 2 + 0] = a;
+        ws[((long long)ng * S + s) * 2 + 1] = b;
+    }
+}
+
+template <bool VEC4>
+__global__ void gn_apply_kernel(const float *x, float *y, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, const double *__restrict__ ws, long long L,
+                                long long slice, int S, int C, int G, float eps, int relu, int out_cs, int out_co) {
+    const int ng = blockIdx.y;
+    const int s = blockIdx.x;
+    const int g = ng % G;
+    const int cg = C / G;
+    double sum = 0, sq = 0;
+    for (int i = 0; i < S; ++i) {  // uniform, L2-resident, S <= 64
+        sum += ws[((long long)ng * S + i) * 2 + 0];
+        sq += ws[((long long)ng * S + i) * 2 + 1];
+    }
+    const double meand = sum / (double)L;
+    double vard = sq / (double)L - meand * meand;
+    if (vard < 0) vard = 0;
+    const float mean = (float)meand;
+    const float rstd = (float)(1.0 / sqrt(vard + (double)eps));
+    const float *p = x + (long long)ng * L;
+    const bool dense = (out_cs == C);
+    // dense: y has x's layout.  sliced: element f of the sample -> y[n][f / C][out_co + f % C]
+    const long long HWC = L * G;
+    float *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
+    const long long lo = (long long)s * slice;
+    const long long hi = min(lo + slice, L);
+    // flat index inside the sample = g*L + i ; channel = that mod C
+    const long long gbase = (long long)g * L;
+    if (VEC4) {
+        for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
+            const int c0 = (int)((gbase + i) % C);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int c = c0 + e;
+                if (c >= C) c -= C;
+                const int j = g * cg + (c % cg);
+                float t = (v[e] - mean) * rstd;
+                if (gamma) t *= gamma[j];
+                if (beta) t += beta[j];
+                o[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
+            else *reinterpret_cast<f32x4 *>(q + ((gbase + i) / C) * out_cs + c0) = o;
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) {
+            const int c = (int)((gbase + i) % C);
+            const int j = g * cg + (c % cg);
+            float t = (p[i] - mean) * rstd;
+            if (gamma) t *= gamma[j];
+            if (beta) t += beta[j];
+            const float r = relu ? fmaxf(t, 0.f) : t;
+            if (dense) q[i] = r;
+            else q[((gbase + i) / C) * out_cs + c] = r;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ml_groupnorm_workspace_bytes(int32_t N, int32_t G) {
+    return (int64_t)N * G * GN_MAX_SPLIT * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const float *beta, int32_t N,
+                                      int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu, int32_t out_cstride,
+                                      int32_t out_coff, void *workspace, void *stream) {
+    ML_REQUIRE(x && y && workspace, "groupnorm: null pointer");
+    ML_REQUIRE(N > 0 && HWC > 0 && C > 0 && G > 0, "groupnorm: bad dims");
+    ML_REQUIRE(C >= G, "groupnorm: Number of groups (%d) cannot be more than the number of channels (%d).", G, C);
+    ML_REQUIRE(C % G == 0, "groupnorm: Number of groups (%d) must be a multiple of the number of channels (%d).", G, C);
+    ML_REQUIRE(HWC % C == 0 && HWC % G == 0, "groupnorm: H*W*C (%lld) must be divisible by C and by G", (long long)HWC);
+    ML_REQUIRE((long long)N * G < 65536, "groupnorm: N*G too large for grid.y");
+    const long long L = HWC / G;
+    const GnPlan plan = gn_plan(L, N * G);
+    ML_REQUIRE(out_cstride >= C && out_coff >= 0 && out_coff + C <= out_cstride, "groupnorm: bad output slice");
+    ML_REQUIRE(out_cstride == C ? out_coff == 0 : true, "groupnorm: dense output must have out_coff 0");
+    const bool vec4 = (L % 4 == 0) && (C % 4 == 0) && (out_cstride % 4 == 0) && (out_coff % 4 == 0) &&
+                      ml_aligned16(x) && ml_aligned16(y);
+    hipStream_t s = (hipStream_t)stream;
+    double *ws = reinterpret_cast<double *>(workspace);
+    const dim3 grid(plan.S, N * G);
+    if (vec4) {
+        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S, C,
+                           G, eps, relu, out_cstride, out_coff);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S,
+                           C, G, eps, relu, out_cstride, out_coff);
+    }
+    ML_CHECK_LAUNCH("groupnorm");
+    return ML_OK;
+}

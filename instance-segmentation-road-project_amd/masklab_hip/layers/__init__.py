@@ -1,0 +1,7 @@
+"""Layer registry of the hot path (mirrors reference engine/layers/__init__.py:5-8)."""
+from .detection import *  # noqa: F401,F403
+from .detection import (BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, FeaturePyramid,
+                        NormalizeBoxes, PriorLayer, RestoreBoxes)
+from .instance import MaskDistribute, MaskSubNet, PyramidRoiAlign
+from .misc import Identity, MoldBatch, ReLU, ResizeLike, SqueezeExcite
+from .semantic import ASPPNetwork, AtrousSeparableConv2D, SegmentationSubNet

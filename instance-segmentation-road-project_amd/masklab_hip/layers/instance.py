@@ -1,0 +1,131 @@
+"""Instance-segmentation layers -- drop-ins for reference engine/layers/instance.py:
+MaskDistribute :32-74, PyramidRoiAlign :77-147, MaskSubNet :158-240."""
+import torch
+
+from .. import ops
+from ..keras_like import Conv2D, Conv2DTranspose, Layer
+from .detection import _TowerMixin
+
+
+class MaskDistribute(Layer):
+    """Pick the pyramid level of every box from its size (reference :32-74):
+    k = clip(floor(log2((sqrt(w*h)+eps)/(base+eps))), 0, max_k); k = -1 for padded rows."""
+
+    def __init__(self, max_k=2, base_size=64, **kwargs):
+        self.max_k = max_k
+        self.base_size = base_size
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        inputs = inputs.contiguous()
+        _, _, kvals = ops.mask_distribute(inputs, self.max_k, self.base_size, has_k=False, want_k=True)
+        return torch.cat([kvals[..., None], inputs], dim=-1)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"max_k": self.max_k, "base_size": self.base_size})
+        return config
+
+
+class PyramidRoiAlign(Layer):
+    """Per level: crop_and_resize the boxes assigned to it and mold by image with -1 padding
+    (reference :77-147).  NOTE: one bilinear sample per output cell (tf.image.crop_and_resize),
+    boxes normalised by the IMAGE (H, W)."""
+
+    def __init__(self, crop_size=(14, 14), max_batch_size=64, **kwargs):
+        self.crop_size = crop_size
+        self.max_batch_size = max_batch_size
+        super().__init__(**kwargs)
+
+    def crop_levels(self, fmap_outputs, rows, image_hw, has_k, base_size=1.0):
+        """rows: [B,cap,6] proposals (has_k=False) or [B,cap,7] dist_boxes (has_k=True).
+        One device->host read (per-level counts) sizes the molded outputs like the reference."""
+        L = len(fmap_outputs)
+        B = rows.shape[0]
+        if B > 32 and self.max_batch_size is not None:
+            raise ValueError("PyramidRoiAlign: MoldBatch supports at most 32 images per call")
+        slots, lcounts, _ = ops.mask_distribute(rows, L - 1, base_size, has_k=has_k)
+        n_l = [max(1, int(v)) for v in lcounts.max(dim=0).values.tolist()]     # the single sync
+        total = sum(n_l)
+        roi_boxes = torch.empty((B, total, 6), dtype=torch.float32, device=rows.device)
+        roi_fmaps, off = [], 0
+        for level, fmap in enumerate(fmap_outputs):
+            roi_fmaps.append(ops.roi_crop_resize(fmap, rows, slots, lcounts, level, n_l[level],
+                                                 tuple(self.crop_size), image_hw, roi_boxes, off))
+            off += n_l[level]
+        return roi_fmaps, roi_boxes
+
+    def call(self, inputs, **kwargs):
+        fmap_outputs, dist_boxes, images = inputs[0], inputs[1], inputs[2]
+        image_hw = (int(images.shape[1]), int(images.shape[2]))
+        roi_fmaps, roi_boxes = self.crop_levels(fmap_outputs, dist_boxes.contiguous(), image_hw, has_k=True)
+        return [roi_fmaps, roi_boxes]
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"crop_size": self.crop_size, "max_batch_size": self.max_batch_size})
+        return config
+
+
+class MaskSubNet(Layer, _TowerMixin):
+    """Mask Prediction Module In RetinaMask (reference :158-240): per level (own weights)
+    depth x [Conv3x3+ReLU ; GN] ; Conv2DTranspose 2x2 s2 + ReLU ; Conv1x1 + sigmoid."""
+
+    def __init__(self, num_blocks, num_classes, num_depth=4, num_features=256, use_separable_conv=False,
+                 expand_ratio=4., use_squeeze_excite=False, squeeze_ratio=16., groups=16, **kwargs):
+        self.num_blocks = num_blocks
+        self.num_classes = num_classes
+        self.num_depth = num_depth
+        self.num_features = num_features
+        self.use_separable_conv = use_separable_conv
+        self.expand_ratio = expand_ratio
+        self.use_squeeze_excite = use_squeeze_excite
+        self.squeeze_ratio = squeeze_ratio
+        self.groups = groups
+        super().__init__(**kwargs)
+        self.blocks = []
+        for idx in range(self.num_blocks):
+            prefix = f'{self.name}/block{idx}'
+            block = self._make_tower(prefix, num_depth, num_features, groups, use_separable_conv, expand_ratio,
+                                     use_squeeze_excite, squeeze_ratio)
+            block.append(Conv2DTranspose(num_features, (2, 2), (2, 2), padding='same', activation='relu',
+                                         kernel_stddev=0.01, name=f'{prefix}/deconv'))
+            block.append(Conv2D(num_classes, (1, 1), padding='same', activation='sigmoid',
+                                kernel_initializer='normal', kernel_stddev=0.01, name=f'{prefix}/output'))
+            self.blocks.append(block)
+
+    def build(self, input_shapes):
+        if not isinstance(input_shapes, list):
+            input_shapes = [input_shapes]
+        out = None
+        for block, shape in zip(self.blocks, input_shapes):
+            s = (None,) + tuple(shape[2:]) if len(shape) == 5 else tuple(shape)
+            out = self._build_chain(block, s)
+        self.built = True
+        return (input_shapes[0][0], None) + tuple(out[1:])
+
+    def children(self):
+        return [l for b in self.blocks for l in b]
+
+    def call(self, inputs, **kwargs):
+        if not isinstance(inputs, list):
+            inputs = [inputs]
+        heads = []
+        for idx, head in enumerate(inputs):
+            B, n = head.shape[0], head.shape[1]
+            x = head.reshape((B * n,) + tuple(head.shape[2:]))          # fold rois into the batch (:211-213)
+            block = self.blocks[idx]
+            x = self._run_tower(block[:-2], x)
+            x = block[-2](x)
+            x = block[-1](x)
+            heads.append(x.reshape((B, n) + tuple(x.shape[1:])))
+        return torch.cat(heads, dim=1) if len(heads) > 1 else heads[0]   # Concatenate(axis=1): data movement
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({
+            "num_blocks": self.num_blocks, "num_classes": self.num_classes, "num_depth": self.num_depth,
+            "num_features": self.num_features, "use_separable_conv": self.use_separable_conv,
+            "expand_ratio": self.expand_ratio, "use_squeeze_excite": self.use_squeeze_excite,
+            "squeeze_ratio": self.squeeze_ratio, "groups": self.groups})
+        return config

@@ -1,0 +1,114 @@
+"""Misc layers of the hot path -- drop-ins for reference engine/layers/misc.py
+(Identity :206-210, ResizeLike :296-319, SqueezeExcite :24-54, MoldBatch :213-293)."""
+import torch
+
+from .. import ops
+from ..keras_like import Dense, Layer
+
+
+class Identity(Layer):
+    """Names a tensor (reference misc.py:206-210)."""
+
+    def call(self, inputs, **kwargs):
+        return inputs
+
+
+class ReLU(Layer):
+    """Placeholder for tf.keras.layers.ReLU: on this path every ReLU is fused into the producing
+    kernel (conv epilogue or GroupNormalization apply pass); calling it standalone is unsupported."""
+
+    def call(self, inputs, **kwargs):
+        raise RuntimeError("ReLU is fused into the producer kernel on the MI355X path")
+
+
+class ResizeLike(Layer):
+    """Change the size of tensor(height & width) to target node (reference misc.py:296-319):
+    tf.compat.v1.image.resize_bilinear(align_corners=True)."""
+
+    def __init__(self, align_corners=True, **kwargs):
+        super().__init__(**kwargs)
+        if not align_corners:
+            raise NotImplementedError("only align_corners=True is used on the hot path")
+        self.align_corners = align_corners
+
+    def call(self, inputs, **kwargs):
+        target = kwargs.get('target')
+        return ops.resize_bilinear_ac(inputs, int(target.shape[1]), int(target.shape[2]),
+                                      add=kwargs.get('add'), out=kwargs.get('out'),
+                                      out_coff=kwargs.get('out_coff', 0))
+
+    def compute_output_shape(self, input_shapes):
+        input_shape, target_shape = input_shapes
+        return input_shape[0], target_shape[1], target_shape[2], input_shape[-1]
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"align_corners": self.align_corners})
+        return config
+
+
+class SqueezeExcite(Layer):
+    """SqueezeAndExcite (reference misc.py:24-54): GAP -> Dense(C//ratio, relu, no bias) ->
+    Dense(C, sigmoid, no bias) -> channel scale.  The two Dense layers are 1x1 MFMA convs on the
+    pooled [B,1,1,C] map; the scale is applied in place."""
+
+    def __init__(self, ratio=16., **kwargs):
+        super().__init__(**kwargs)
+        self.ratio = ratio
+        self.dense1 = self.dense2 = None
+
+    def build(self, input_shape):
+        n_channel = int(input_shape[-1])
+        self.dense1 = Dense(int(n_channel // self.ratio), activation='relu', kernel_initializer='he_normal',
+                            name=f"{self.name}/dense1")
+        self.dense2 = Dense(n_channel, activation='sigmoid', kernel_initializer='glorot_normal',
+                            name=f"{self.name}/dense2")
+        s = self.dense1.build((input_shape[0], 1, 1, n_channel))
+        self.dense2.build(s)
+        self.built = True
+        return input_shape
+
+    def children(self):
+        return [l for l in (self.dense1, self.dense2) if l is not None]
+
+    def call(self, inputs, **kwargs):
+        se = ops.global_mean(inputs)
+        se = self.dense2(self.dense1(se))
+        out = inputs.clone() if kwargs.get("keep_input", True) else inputs
+        return ops.scale_channels_(out, se)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"ratio": self.ratio})
+        return config
+
+
+class MoldBatch(Layer):
+    """Group rows by image and pad with -1 (reference misc.py:213-293).  The fused kernels
+    (detection proposal / RoI crop) emit molded tensors directly; this standalone layer covers
+    the remaining call sites and is pure data movement (row scatter), done with torch indexing."""
+
+    def __init__(self, max_batch_size=None, **kwargs):
+        super().__init__(**kwargs)
+        self.max_batch_size = max_batch_size
+
+    def call(self, inputs, **kwargs):
+        batch_indices = kwargs.get('batch_indices').to(torch.int64)
+        batch_size = int(kwargs.get('batch_size'))
+        if self.max_batch_size is not None and batch_size > 32:
+            raise ValueError("MoldBatch partitions into 32 slots (reference misc.py:275): batch <= 32")
+        counts = torch.bincount(batch_indices, minlength=batch_size)
+        n = max(1, int(counts.max().item()) if counts.numel() else 1)
+        out = torch.full((batch_size, n) + tuple(inputs.shape[1:]), -1.0, dtype=inputs.dtype, device=inputs.device)
+        if inputs.shape[0]:
+            start = torch.cumsum(counts, 0) - counts
+            order = torch.argsort(batch_indices, stable=True)
+            sorted_b = batch_indices[order]
+            rank = torch.arange(inputs.shape[0], device=inputs.device) - start[sorted_b]
+            out[sorted_b, rank] = inputs[order]
+        return out
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"max_batch_size": self.max_batch_size})
+        return config

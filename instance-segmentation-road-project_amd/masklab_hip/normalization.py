@@ -1,0 +1,85 @@
+"""GroupNormalization -- drop-in for reference engine/normalization.py (the Keras layer),
+running the chunk-norm HIP kernel (csrc/groupnorm.hip).
+
+The reference layer with axis=-1 on NHWC does NOT group channels: it reshapes [N,H,W,C]
+row-major to [N,G,H,W,C/G] and normalises over axes (2,3,4) (normalization.py:123-143), i.e.
+each sample's flat H*W*C vector is cut into G contiguous chunks; gamma/beta are indexed
+g*(C/G) + (c mod C/G) (:151-156).  That exact behaviour is reproduced.
+"""
+import numpy as np
+
+from . import ops
+from .keras_like import Layer
+
+
+class GroupNormalization(Layer):
+    def __init__(self, groups=32, axis=-1, epsilon=1e-5, center=True, scale=True,
+                 beta_initializer="zeros", gamma_initializer="ones", beta_regularizer=None,
+                 gamma_regularizer=None, beta_constraint=None, gamma_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        if axis not in (-1, 3):
+            raise NotImplementedError("GroupNormalization: only axis=-1 (NHWC) is on the hot path")
+        self.supports_masking = True
+        self.groups = groups
+        self.axis = axis
+        self.epsilon = epsilon
+        self.center = center
+        self.scale = scale
+        self.beta_initializer = beta_initializer
+        self.gamma_initializer = gamma_initializer
+        self.beta_regularizer = beta_regularizer
+        self.gamma_regularizer = gamma_regularizer
+        self.beta_constraint = beta_constraint
+        self.gamma_constraint = gamma_constraint
+        self.gamma = self.beta = None
+
+    def build(self, input_shape):
+        dim = input_shape[self.axis]
+        # same checks / messages as reference normalization.py:78-92
+        if dim is None:
+            raise ValueError('Axis ' + str(self.axis) + ' of input tensor should have a defined dimension '
+                             'but the layer received an input with shape ' + str(input_shape) + '.')
+        if dim < self.groups:
+            raise ValueError('Number of groups (' + str(self.groups) + ') cannot be '
+                             'more than the number of channels (' + str(dim) + ').')
+        if dim % self.groups != 0:
+            raise ValueError('Number of groups (' + str(self.groups) + ') must be a '
+                             'multiple of the number of channels (' + str(dim) + ').')
+        self.dim = int(dim)
+        # synthetic-weight init draws non-trivial gamma/beta so parity tests exercise the indexing
+        if self.scale:
+            self.add_weight("gamma", (dim,), "uniform", low=0.5, high=1.5)
+        if self.center:
+            self.add_weight("beta", (dim,), "normal", stddev=0.1)
+        self.built = True
+        return input_shape
+
+    def _load_own(self, weights, device):
+        import torch
+        self.gamma = torch.from_numpy(self._get(weights, "gamma")).to(device) if self.scale else None
+        self.beta = torch.from_numpy(self._get(weights, "beta")).to(device) if self.center else None
+
+    def call(self, inputs, fuse_relu=False, inplace=False, **kwargs):
+        if not self.built:
+            self.build(tuple(inputs.shape))
+        if (self.scale and self.gamma is None) or (self.center and self.beta is None):
+            raise RuntimeError(f"layer '{self.name}' has no weights loaded")
+        return ops.groupnorm_chunk(inputs, self.gamma, self.beta, self.groups, self.epsilon, relu=fuse_relu,
+                                   out=inputs if inplace else None)
+
+    def get_config(self):
+        config = {
+            'groups': self.groups, 'axis': self.axis, 'epsilon': self.epsilon, 'center': self.center,
+            'scale': self.scale, 'beta_initializer': self.beta_initializer,
+            'gamma_initializer': self.gamma_initializer, 'beta_regularizer': self.beta_regularizer,
+            'gamma_regularizer': self.gamma_regularizer, 'beta_constraint': self.beta_constraint,
+            'gamma_constraint': self.gamma_constraint,
+        }
+        base = super().get_config()
+        return dict(list(base.items()) + list(config.items()))
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+
+__all__ = ["GroupNormalization"]

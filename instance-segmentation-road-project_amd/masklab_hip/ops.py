@@ -1,0 +1,272 @@
+"""Operator launchers: torch tensors (device memory + streams only) -> libmasklab_hip.so.
+
+Every function enqueues HIP kernels on torch's CURRENT stream and returns the output tensor.
+Tensors are NHWC float32, contiguous.  A `(buffer, channel_offset)` pair addresses a channel
+slice of a wider buffer so concat / add are fused into the producing kernel.
+There is no torch compute and no CPU fallback here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .packing import PackedConv, resolve_padding
+
+_ws_cache = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"masklab_hip: `{name}` must be a CUDA/HIP torch tensor -- the product path "
+                           f"runs only on the MI355X kernels (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"masklab_hip: `{name}` must be contiguous NHWC")
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); 256-byte aligned by the torch allocator."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+class DeviceConv:
+    """A PackedConv uploaded to the GPU."""
+
+    def __init__(self, packed: PackedConv, device):
+        self.p = packed
+        self.wgt = torch.from_numpy(np.ascontiguousarray(packed.wgt)).to(device)
+        self.bias = None if packed.bias is None else torch.from_numpy(packed.bias).to(device)
+
+
+def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
+           residual=None, out=None, out_coff=0, in_coff=0, out_view=None):
+    """ml_conv2d_f32.  `x` [B,H,W,Cbuf]; reads channels [in_coff, in_coff+cin).  Writes into
+    `out[..., out_coff:out_coff+cout]` when given, else allocates.  `out_view=(tensor, elem_off,
+    cstride, bstride)` writes image b's pixels at tensor.data + elem_off + b*bstride with row
+    pitch cstride (used to land a level's head directly in the concatenated prediction)."""
+    lib = _lib.load()
+    p = dc.p
+    _require_dev(x, "x")
+    B, H, W, Cbuf = x.shape
+    if p.cpp_shift != 30:
+        if Cbuf != p.cin_buffer:
+            raise ValueError(f"row-span conv expects a {p.cin_buffer}-channel padded image, got {Cbuf}")
+    elif not p.group_cin_step and in_coff + p.span > Cbuf:
+        raise ValueError(f"conv2d: input has {Cbuf} channels, kernel needs [{in_coff},{in_coff + p.span})")
+    Ho, Wo, pt, pl = resolve_padding(H, W, p.kh_real, p.kw_real, stride, dilation, padding)
+    co = p.cout // 4 if p.shuffle2x2 else p.cout
+    oh, ow = (2 * Ho, 2 * Wo) if p.shuffle2x2 else (Ho, Wo)
+    d = _lib.ConvDesc()
+    ret = None
+    if out_view is not None:
+        vt, elem_off, vcs, vbs = out_view
+        _require_dev(vt, "out_view")
+        if p.shuffle2x2 or vcs < co or vbs < oh * ow * vcs:
+            raise ValueError("conv2d: bad out_view")
+        if elem_off + (B - 1) * vbs + oh * ow * vcs > vt.numel():
+            raise ValueError("conv2d: out_view exceeds the destination tensor")
+        ret = vt
+    elif out is None:
+        out = torch.empty((B, oh, ow, co), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    else:
+        _require_dev(out, "out")
+        if tuple(out.shape[:3]) != (B, oh, ow):
+            raise ValueError(f"conv2d: out buffer {tuple(out.shape)} does not match {(B, oh, ow)}")
+    d.in_, d.wgt, d.bias = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
+    if out_view is not None:
+        d.out = vt.data_ptr() + 4 * elem_off
+        d.out_cstride, d.out_coff, d.out_bstride = vcs, 0, vbs
+    else:
+        d.out = out.data_ptr()
+        d.out_cstride, d.out_coff, d.out_bstride = out.shape[3], out_coff, 0
+        ret = out
+    if residual is not None:
+        _require_dev(residual, "residual")
+        if tuple(residual.shape[:3]) != (B, Ho, Wo):
+            raise ValueError("conv2d: residual spatial shape mismatch")
+        d.residual, d.res_cstride, d.res_coff = residual.data_ptr(), residual.shape[3], 0
+    d.B, d.H, d.W = B, H, W
+    d.in_cstride, d.in_coff = Cbuf, in_coff
+    d.span, d.span_pad, d.cpp_shift = p.span, p.span_pad, p.cpp_shift
+    d.Ho, d.Wo = Ho, Wo
+    d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
+    d.cout, d.n_pad = p.cout, p.n_pad
+    d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
+    _lib.check(lib.ml_conv2d_f32(C.byref(d), _stream()), "ml_conv2d_f32")
+    return ret
+
+
+def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, out=None, out_coff=0):
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    Ho, Wo, pt, pl = resolve_padding(H, W, 3, 3, stride, dilation, padding)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    _lib.check(lib.ml_dwconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, Cc, 0,
+                                    out.shape[3], out_coff, Ho, Wo, stride, dilation, pt, pl, act, _stream()),
+               "ml_dwconv3x3_f32")
+    return out
+
+
+def maxpool3x3s2(x, pad=1):
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    Ho = (H + 2 * pad - 3) // 2 + 1
+    Wo = (W + 2 * pad - 3) // 2 + 1
+    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ml_maxpool3x3s2_f32(_ptr(x), _ptr(out), B, H, W, Cc, Ho, Wo, pad, pad, _stream()),
+               "ml_maxpool3x3s2_f32")
+    return out
+
+
+def preprocess(images, flip, mean, divisor, shift, out_channels=4):
+    """BackBonePreProcess fused with the NHWC4 repack.  images: uint8 or float32 [B,H,W,3]."""
+    lib = _lib.load()
+    _require_dev(images, "images")
+    if images.dtype not in (torch.uint8, torch.float32):
+        raise TypeError("images must be uint8 or float32")
+    B, H, W, ch = images.shape
+    if ch != 3:
+        raise ValueError("images must have 3 channels (RGB, 0..255)")
+    out = torch.empty((B, H, W, out_channels), dtype=torch.float32, device=images.device)
+    _lib.check(lib.ml_preprocess_f32(_ptr(images), int(images.dtype == torch.uint8), _ptr(out), B * H * W,
+                                     out_channels, int(flip), float(mean[0]), float(mean[1]), float(mean[2]),
+                                     float(divisor), float(shift), _stream()), "ml_preprocess_f32")
+    return out
+
+
+def groupnorm_chunk(x, gamma, beta, groups, eps=1e-5, relu=False, out=None, out_coff=0):
+    """`out` may be x itself (in place), a same-shape tensor, or a wider concat buffer
+    [N,H,W,Cbuf] written at channels [out_coff, out_coff+C)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    N = x.shape[0]
+    Cc = x.shape[-1]
+    hwc = x.numel() // N
+    if out is None:
+        out = torch.empty_like(x)
+    _require_dev(out, "out")
+    out_cs = out.shape[-1]
+    if out_cs == Cc:
+        if out.numel() != x.numel() or out_coff != 0:
+            raise ValueError("groupnorm: dense output must match the input size")
+    elif tuple(out.shape[:-1]) != tuple(x.shape[:-1]):
+        raise ValueError("groupnorm: concat buffer spatial shape mismatch")
+    ws = workspace(lib.ml_groupnorm_workspace_bytes(N, groups), x.device, "gn")
+    _lib.check(lib.ml_groupnorm_chunk_f32(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
+                                          float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()),
+               "ml_groupnorm_chunk_f32")
+    return out
+
+
+def resize_bilinear_ac(x, oh, ow, add=None, out=None, out_coff=0):
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    add_cs = add.shape[3] if add is not None else 0
+    _lib.check(lib.ml_resize_bilinear_ac_f32(_ptr(x), _ptr(add), _ptr(out), B, H, W, Cc, Cc, 0, oh, ow,
+                                             add_cs, 0, out.shape[3], out_coff, _stream()),
+               "ml_resize_bilinear_ac_f32")
+    return out
+
+
+def global_mean(x):
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, 1, 1, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ml_global_mean_f32(_ptr(x), _ptr(out), B, H * W, Cc, _stream()), "ml_global_mean_f32")
+    return out
+
+
+def scale_channels_(x, s):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    _lib.check(lib.ml_scale_channels_f32(_ptr(x), _ptr(s), B, H * W, Cc, _stream()), "ml_scale_channels_f32")
+    return x
+
+
+def restore_boxes(loc_pred, priors_i32):
+    lib = _lib.load()
+    _require_dev(loc_pred, "loc_pred")
+    B, A, _ = loc_pred.shape
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=loc_pred.device)
+    _lib.check(lib.ml_restore_boxes_f32(_ptr(loc_pred), _ptr(priors_i32), _ptr(boxes), B, A, _stream()),
+               "ml_restore_boxes_f32")
+    return boxes
+
+
+def detection_proposal(cls_pred, boxes, min_confidence, nms_iou, post_iou, max_out, want_kept=False):
+    """Fixed-capacity DetectionProposal: -> proposed [B,max_out,6] (-1 padded), counts [B] int32
+    (device), kept [B,max_out,2] int32 or None."""
+    lib = _lib.load()
+    _require_dev(cls_pred, "cls_pred")
+    _require_dev(boxes, "boxes")
+    B, A, Cn = cls_pred.shape
+    dev = cls_pred.device
+    proposed = torch.empty((B, max_out, 6), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    kept = torch.empty((B, max_out, 2), dtype=torch.int32, device=dev) if want_kept else None
+    ws = workspace(lib.ml_detection_workspace_bytes(B, A, Cn, max_out), dev, "det")
+    _lib.check(lib.ml_detection_proposal_f32(_ptr(cls_pred), _ptr(boxes), _ptr(proposed), _ptr(counts), _ptr(kept),
+                                             B, A, Cn, float(min_confidence), float(nms_iou), float(post_iou),
+                                             int(max_out), _ptr(ws), _stream()), "ml_detection_proposal_f32")
+    return proposed, counts, kept
+
+
+def mask_distribute(rows, max_k, base_size, has_k=False, want_k=False):
+    """rows [B,cap,6] (has_k=False: k computed per MaskDistribute) or [B,cap,7] dist_boxes
+    (has_k=True).  -> level_slots [B,L,cap] int32, level_counts [B,L] int32, kvals [B,cap] or None."""
+    lib = _lib.load()
+    _require_dev(rows, "rows")
+    B, cap, rs = rows.shape
+    L = max_k + 1
+    slots = torch.empty((B, L, cap), dtype=torch.int32, device=rows.device)
+    lcounts = torch.empty((B, L), dtype=torch.int32, device=rows.device)
+    kvals = torch.empty((B, cap), dtype=torch.float32, device=rows.device) if want_k else None
+    _lib.check(lib.ml_mask_distribute_i32(_ptr(rows), rs, int(has_k), _ptr(kvals), _ptr(slots), _ptr(lcounts), B, cap,
+                                          max_k, float(base_size), _stream()), "ml_mask_distribute_i32")
+    return slots, lcounts, kvals
+
+
+def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, roi_boxes, box_off):
+    """rows [B,cap,6] (cx,cy,w,h,cls,conf) or [B,cap,7] dist_boxes (k first)."""
+    lib = _lib.load()
+    _require_dev(fmap, "fmap")
+    B, Hf, Wf, Cc = fmap.shape
+    cap, rs = rows.shape[1], rows.shape[2]
+    roff = rs - 6
+    L = slots.shape[1]
+    ch, cw = crop_size
+    out = torch.empty((B, n_l, ch, cw, Cc), dtype=torch.float32, device=fmap.device)
+    _lib.check(lib.ml_roi_crop_resize_f32(_ptr(fmap), _ptr(rows), rs, roff, _ptr(slots), _ptr(lcounts), _ptr(out),
+                                          _ptr(roi_boxes), B, Hf, Wf, Cc, cap, L, level, n_l, ch, cw,
+                                          float(img_hw[0]), float(img_hw[1]), box_off, roi_boxes.shape[1], _stream()),
+               "ml_roi_crop_resize_f32")
+    return out
+
+
+def fill_(x, v):
+    lib = _lib.load()
+    _lib.check(lib.ml_fill_f32(_ptr(x), float(v), x.numel(), _stream()), "ml_fill_f32")
+    return x

@@ -1,0 +1,267 @@
+"""Model build API -- drop-in for the inference half of reference engine/retinamasklab.py:
+build_backbone_network :19-37, build_detection_network :40-112, build_instance_network :115-157,
+build_semantic_network :160-198, construct_inference_network :420-495, find_layer_name :646-649.
+Same function names, argument meaning and return structure; the returned model runs eagerly on
+the MI355X kernels.  Training-only pieces (construct_trainer_network, losses, dataset) are out of
+scope of the accelerated path.
+"""
+import numpy as np
+import torch
+
+from . import backbone
+from . import keras_like as K
+from .config import ModelConfiguration
+from .layers import (ASPPNetwork, BoxRegressionSubNet, ClassificationSubNet, DetectionProposal,
+                     FeaturePyramid, MaskDistribute, MaskSubNet, PriorLayer, PyramidRoiAlign,
+                     RestoreBoxes, SegmentationSubNet)
+from .prior import PriorBoxes
+
+VERBOSE = False
+
+
+def _say(*lines):
+    if VERBOSE:
+        print("\n".join(lines))
+
+
+def build_backbone_network(configuration: ModelConfiguration):
+    config = configuration.backbone
+    model = backbone.load_backbone(config.backbone_type, config.backbone_outputs, config.num_features)
+    _say("Backbone Network Summary", "------------------------",
+         f"* Backbone Type : {config.backbone_type}", f"* Backbone outputs : {config.backbone_outputs}",
+         f"* Num features of Backbone Additional Layers: {config.num_features}", "------------------------\n")
+    return model
+
+
+def build_detection_network(configuration: ModelConfiguration):
+    config = configuration.detection
+    num_backbone_outputs = len(configuration.backbone.backbone_outputs)
+    num_classes = len(configuration.dataset.instance_labels)
+    # the output block's name encodes its stride (= number of stride-2 layers), reference :46-48
+    prior_strides = [2 ** int(output_name[-1]) for output_name in configuration.backbone.backbone_outputs]
+    prior_sizes = [4 * stride for stride in prior_strides]
+    prior = PriorBoxes(strides=prior_strides, sizes=prior_sizes, pr_scales=config.pr_scales,
+                       pr_ratios=config.pr_ratios)
+    prior_subnet = PriorLayer(prior)
+    assert len(set(config.feature_pyramid_inputs) - {'C1', 'C2', 'C3', 'C4', 'C5', 'P6', 'P7'}) == 0, \
+        "feature pyramid inputs must be drawn from C1~C5, P6, P7"
+    feature_pyramid_strides = [2 ** int(name[1]) for name in config.feature_pyramid_inputs]
+    fpn_subnet = FeaturePyramid(strides=feature_pyramid_strides, num_features=config.num_features)
+    cls_subnet = ClassificationSubNet(num_blocks=num_backbone_outputs, num_classes=num_classes,
+                                      num_depth=config.num_depth, num_features=config.num_features,
+                                      num_priors=len(prior), use_separable_conv=config.use_separable_conv,
+                                      expand_ratio=config.expand_ratio,
+                                      use_squeeze_excite=config.use_squeeze_excite,
+                                      squeeze_ratio=config.squeeze_ratio, groups=config.groups)
+    # NB reference quirk kept (:95): the box tower's squeeze-excite flag is `use_separable_conv`
+    loc_subnet = BoxRegressionSubNet(num_blocks=num_backbone_outputs, num_depth=config.num_depth,
+                                     num_features=config.num_features, num_priors=len(prior),
+                                     use_separable_conv=config.use_separable_conv,
+                                     expand_ratio=config.expand_ratio,
+                                     use_squeeze_excite=config.use_separable_conv,
+                                     squeeze_ratio=config.squeeze_ratio, groups=config.groups)
+    return prior_subnet, fpn_subnet, cls_subnet, loc_subnet
+
+
+def build_instance_network(configuration: ModelConfiguration):
+    num_classes = len(configuration.dataset.instance_labels)
+    config = configuration.instance
+    restore_subnet = RestoreBoxes()
+    distribute_subnet = MaskDistribute(max_k=config.max_k, base_size=config.base_size)
+    pyramid_roi_align = PyramidRoiAlign(crop_size=config.crop_size)
+    # NB reference quirk kept (:139): expand_ratio receives `use_separable_conv`
+    mask_subnet = MaskSubNet(num_blocks=config.max_k + 1, num_classes=num_classes, num_depth=config.num_depth,
+                             num_features=config.num_features, use_separable_conv=config.use_separable_conv,
+                             expand_ratio=config.use_separable_conv, use_squeeze_excite=config.use_squeeze_excite,
+                             squeeze_ratio=config.squeeze_ratio, groups=config.groups)
+    return restore_subnet, distribute_subnet, pyramid_roi_align, mask_subnet
+
+
+def build_semantic_network(configuration: ModelConfiguration):
+    config = configuration.semantic
+    num_classes = len(configuration.dataset.semantic_labels)
+    aspp_subnet = ASPPNetwork(num_features=config.num_aspp_features, atrous_rate=config.atrous_rate,
+                              groups=config.atrous_groups)
+    # NB reference quirk kept (:179): expand_ratio receives `use_separable_conv`
+    seg_subnet = SegmentationSubNet(num_depth=config.num_depth, num_features=config.num_features,
+                                    num_skip_features=config.num_skip_features, num_classes=num_classes,
+                                    use_separable_conv=config.use_separable_conv,
+                                    expand_ratio=config.use_separable_conv,
+                                    use_squeeze_excite=config.use_squeeze_excite,
+                                    squeeze_ratio=config.squeeze_ratio, groups=config.groups)
+    return aspp_subnet, seg_subnet
+
+
+class InferenceModel(K.Layer):
+    """The Keras functional `Model(images -> [cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred])`
+    of reference :420-495, executed eagerly.  Output list shrinks like the reference when a head
+    group is None."""
+
+    def __init__(self, configuration, backbone_network, detection_networks=None, semantic_networks=None,
+                 instance_networks=None, name='inference'):
+        super().__init__(name=name)
+        self.configuration = configuration
+        self.backbone_network = backbone_network
+        self.detection_networks = detection_networks
+        self.semantic_networks = semantic_networks
+        self.instance_networks = instance_networks if detection_networks is not None else None
+        self.detection_proposal = None
+        self.output_names = []
+        if detection_networks is not None:
+            self.output_names += ['cls_pred', 'loc_pred']
+            if self.instance_networks is not None:
+                det_config = configuration.detection
+                # re-instantiated from config.detection.* every time (reference :459-466)
+                self.detection_proposal = DetectionProposal(
+                    min_confidence=det_config.min_confidence, nms_iou_threshold=det_config.nms_iou_threshold,
+                    post_iou_threshold=det_config.post_iou_threshold,
+                    nms_max_output_size=det_config.nms_max_output_size,
+                    max_batch_size=configuration.train.inference_batch_size)
+                self.output_names += ['roi_boxes', 'roi_masks']
+        if semantic_networks is not None:
+            self.output_names.append('seg_pred')
+        self.layers = self._flat_layers()
+        self.device = None
+        self.last_detections = None
+        self._build_shapes()
+
+    # ---- structure
+    def _flat_layers(self):
+        layers = [self.backbone_network]
+        for grp in (self.detection_networks, self.instance_networks, self.semantic_networks):
+            if grp is not None:
+                layers += list(grp)
+        if self.detection_proposal is not None:
+            layers.append(self.detection_proposal)
+        return layers
+
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError(f"No such layer: {name}")
+
+    def children(self):
+        return self.layers
+
+    def weight_specs(self):
+        out = {}
+        for l in self.layers:
+            out.update(l.weight_specs())
+        return out
+
+    def _build_shapes(self):
+        bb = self.backbone_network
+        shapes = bb.output_shapes if bb.built else bb.build((None, None, None, 3))
+        by_name = dict(zip(bb.output_names, shapes))
+        if self.detection_networks is not None:
+            det_config = self.configuration.detection
+            _, fpn, cls, loc = self.detection_networks
+            fpn_in = [by_name[n] for n in bb.output_names if n in det_config.feature_pyramid_inputs]
+            rest = [by_name[n] for n in bb.output_names if n not in det_config.feature_pyramid_inputs]
+            feats = fpn.build(fpn_in) + rest
+            cls.build(feats)
+            loc.build(feats)
+            if self.instance_networks is not None:
+                ins = self.configuration.instance
+                mask = self.instance_networks[3]
+                ch, cw = ins.crop_size
+                mask.build([(None, None, ch, cw, f[-1]) for f in feats[:ins.max_k + 1]])
+        if self.semantic_networks is not None:
+            seg_config = self.configuration.semantic
+            aspp, seg = self.semantic_networks
+            a = aspp.build(by_name[seg_config.aspp_input_name])
+            seg.build([a, by_name[seg_config.skip_input_name]])
+        self.built = True
+
+    # ---- weights
+    def init_weights(self, seed=0):
+        """Random weights from each layer's initializer (what a fresh Keras model has), keyed and
+        seeded by weight name so the result is independent of construction order."""
+        return K.init_weights(self.weight_specs(), seed)
+
+    def load_weights(self, weights, device="cuda"):
+        self.device = torch.device(device)
+        for l in self.layers:
+            l.load_weights(weights, self.device)
+        return self
+
+    # ---- forward (reference :431-491)
+    def call(self, images, **kwargs):
+        cfg = self.configuration
+        if not isinstance(images, torch.Tensor):
+            images = torch.as_tensor(np.asarray(images))
+        if self.device is None:
+            raise RuntimeError("InferenceModel: call load_weights(weights, device) first")
+        images = images.to(self.device).contiguous()
+        bb = self.backbone_network
+        feats = bb(images)
+        by_name = dict(zip(bb.output_names, feats))
+        outputs = []
+        if self.detection_networks is not None:
+            det_config = cfg.detection
+            prior_subnet, fpn_subnet, cls_subnet, loc_subnet = self.detection_networks
+            pr_boxes = prior_subnet(images)
+            fpn_inputs = [by_name[n] for n in bb.output_names if n in det_config.feature_pyramid_inputs]
+            without_fpn = [by_name[n] for n in bb.output_names if n not in det_config.feature_pyramid_inputs]
+            feature_outputs = fpn_subnet(fpn_inputs) + without_fpn
+            cls_pred = cls_subnet(feature_outputs)
+            loc_pred = loc_subnet(feature_outputs)
+            outputs += [cls_pred, loc_pred]
+            if self.instance_networks is not None:
+                restore_subnet, distribute_subnet, pyramid_roi_align, mask_subnet = self.instance_networks
+                restored_boxes = restore_subnet([loc_pred, pr_boxes])
+                # fused DetectionProposal -> MaskDistribute -> PyramidRoiAlign in fixed capacity:
+                # the only host read is the per-level RoI count that sizes the molded outputs.
+                proposed, counts, kept = self.detection_proposal.propose_fixed(
+                    cls_pred, restored_boxes, want_kept=kwargs.get("want_kept", False))
+                n_levels = cfg.instance.max_k + 1
+                if distribute_subnet.max_k + 1 != n_levels:
+                    raise ValueError("MaskDistribute.max_k does not match config.instance.max_k")
+                image_hw = (int(images.shape[1]), int(images.shape[2]))
+                roi_fmaps, roi_boxes = pyramid_roi_align.crop_levels(
+                    feature_outputs[:n_levels], proposed, image_hw, has_k=False,
+                    base_size=distribute_subnet.base_size)
+                roi_masks = mask_subnet(roi_fmaps)
+                outputs += [roi_boxes, roi_masks]
+                self.last_detections = dict(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes)
+        if self.semantic_networks is not None:
+            seg_config = cfg.semantic
+            aspp_subnet, seg_subnet = self.semantic_networks
+            aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
+            outputs.append(seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]]))
+        return outputs
+
+    def predict(self, images, **kwargs):
+        """Keras `Model.predict`: numpy in, list of numpy out."""
+        outs = self.call(images, **kwargs)
+        torch.cuda.synchronize(self.device)
+        return [o.cpu().numpy() for o in outs]
+
+
+def construct_inference_network(configuration: ModelConfiguration, backbone_network, detection_networks=None,
+                                semantic_networks=None, instance_networks=None):
+    """Same signature as reference :420-424."""
+    return InferenceModel(configuration, backbone_network, detection_networks=detection_networks,
+                          semantic_networks=semantic_networks, instance_networks=instance_networks)
+
+
+def construct_masklab_networks(config: ModelConfiguration, with_trainer=False):
+    """Reference :201-220 returns (trainer, inference); the training graph is outside the
+    accelerated path, so the first element is None."""
+    K.clear_session()
+    backbone_network = build_backbone_network(config)
+    detection_networks = build_detection_network(config)
+    instance_networks = build_instance_network(config)
+    semantic_networks = build_semantic_network(config)
+    if with_trainer:
+        raise NotImplementedError("construct_trainer_network is training-only (out of the hot-path scope)")
+    inference = construct_inference_network(configuration=config, backbone_network=backbone_network,
+                                            detection_networks=detection_networks,
+                                            semantic_networks=semantic_networks,
+                                            instance_networks=instance_networks)
+    return None, inference
+
+
+def find_layer_name(re_format, model):
+    return sorted([layer.name for layer in model.layers if re_format.match(layer.name)])

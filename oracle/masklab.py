@@ -1,0 +1,468 @@
+"""CPU ORACLE (test infrastructure only) -- the MaskLab inference forward in NumPy.
+
+PARITY UNPINNED (see oracle/tfops.py header): a restatement of the reference's
+layer code, written from the reference text; the reference itself cannot run here
+(TensorFlow absent) and ships no fixtures for this path.  Only the anchor table is
+pinned against the reference (tests/golden/prior_tables.npz).
+
+Each function cites the reference file:line it follows.  `weights` is a flat dict
+{"<layer name>/<weight name>": ndarray} in Keras layouts:
+Conv2D kernel [kh,kw,cin,cout] (+bias), DepthwiseConv2D depthwise_kernel
+[kh,kw,cin,mult], Conv2DTranspose kernel [kh,kw,cout,cin], BN
+gamma/beta/moving_mean/moving_variance, GN gamma/beta.  Layer names are the
+reference's explicit names where it gives them and a deterministic hierarchical
+name (`<layer>/block<i>/conv<j>` ...) where Keras would auto-number.
+
+`config` is any object exposing the reference's ModelConfiguration attribute tree
+(engine/config.py:47-116).  The oracle never imports the product package.
+"""
+import numpy as np
+
+from . import tfops as T
+
+F32 = np.float32
+
+
+# =========================================================================== anchors
+def prior_table(strides, sizes, pr_scales, pr_ratios):
+    """engine/prior.py:55-67: rows (stride, w, h) looping size/stride -> scale -> ratio,
+    w=round(size*s*sqrt(r)), h=round(size*s/sqrt(r)) (np.round = half-to-even)."""
+    rows = []
+    for size, stride in zip(sizes, strides):
+        for s in pr_scales:
+            for r in pr_ratios:
+                w = int(np.round(size * s * np.sqrt(r)))
+                h = int(np.round(size * s / np.sqrt(r)))
+                rows.append((stride, w, h))
+    return np.asarray(rows, np.int64).reshape(-1, 3)
+
+
+def prior_boxes(table, height, width, padding="same"):
+    """PriorLayer.call, engine/layers/detection.py:269-298 (without the batch tile):
+    per stride group ascending (:260-262); per row: centres range(stride//2,
+    ceil(H/stride)*stride, stride) (:276-284); meshgrid(xs,ys); rows stacked on axis 2
+    -> [Hl,Wl,n,4] -> (-1,4) (:289-293); levels concatenated (:295)."""
+    out = []
+    for stride in sorted(set(table[:, 0].tolist())):
+        rows = table[table[:, 0] == stride]
+        boxes = []
+        for _, bw, bh in rows:
+            if padding == "same":
+                th = int(np.ceil(height / stride) * stride)
+                tw = int(np.ceil(width / stride) * stride)
+            else:
+                th = int(np.floor(height / stride) * stride)
+                tw = int(np.floor(width / stride) * stride)
+            ys = np.arange(stride // 2, th, stride)
+            xs = np.arange(stride // 2, tw, stride)
+            xs, ys = np.meshgrid(xs, ys)
+            boxes.append(np.stack((xs, ys, np.ones_like(xs) * bw, np.ones_like(ys) * bh), axis=-1))
+        boxes = np.stack(boxes, axis=2).reshape(-1, 4)
+        out.append(boxes)
+    return np.concatenate(out, axis=0).astype(np.int32)
+
+
+# =========================================================================== backbone
+def backbone_preprocess(x, rgb=True, mean_shift=False, normalize=0):
+    """BackBonePreProcess.call, engine/backbone/base.py:57-75."""
+    dt = x.dtype
+    if rgb:
+        mean = np.asarray([123.68, 116.779, 103.939], dt)
+        std = np.asarray([0.225, 0.224, 0.229], dt)
+    else:
+        mean = np.asarray([103.939, 116.779, 123.68], dt)
+        std = np.asarray([0.229, 0.224, 0.225], dt)
+    if not rgb:
+        x = x[..., ::-1]
+    if mean_shift:
+        x = x - mean
+    if normalize == 1:
+        return x / dt.type(255.)
+    if normalize == 2:
+        return x / dt.type(127.5) if mean_shift else x / dt.type(127.5) - dt.type(1.)
+    if normalize == 3:
+        return (x / dt.type(255.)) / std
+    return x
+
+
+def _bn(x, w, name, eps):
+    return T.batch_norm(x, w.get(name + "/gamma"), w[name + "/beta"],
+                        w[name + "/moving_mean"], w[name + "/moving_variance"], eps)
+
+
+def grouped_conv_literal(x, dw_kernel, groups, c, stride):
+    """ResNeXt grouped 3x3 exactly as the reference spells it (ResNext.py:212-219):
+    ZeroPadding2D(1) + DepthwiseConv2D(depth_multiplier=c, 'valid') (:213-215), then
+    SplitGroups reshape [...,groups,c,c] (:33-37), ReduceGroups reduce_sum(axis=-2)
+    (:54), MergeGroups reshape [...,filters] (:66-71)."""
+    y = T.depthwise_conv2d(x, dw_kernel, stride=stride, padding=((1, 1), (1, 1)))
+    B, H, W, _ = y.shape
+    y = y.reshape(B, H, W, groups, c, c).sum(axis=-2)
+    return y.reshape(B, H, W, groups * c)
+
+
+def grouped_conv_fast(x, dw_kernel, groups, c, stride):
+    """Same arithmetic as grouped_conv_literal without the c-times-larger temporary:
+    out[g*c+m] = sum_i conv(x[g*c+i], K[..,g*c+i,m]).  Cross-checked
+    against the literal form in tests; used for large inputs / CPU timing."""
+    B, H, W, C = x.shape
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    Ho = (H + 2 - 3) // stride + 1
+    Wo = (W + 2 - 3) // stride + 1
+    k = dw_kernel.astype(x.dtype).reshape(3, 3, groups, c, c)  # [kh,kw,g,i,m]
+    out = np.zeros((B, Ho, Wo, groups, c), x.dtype)
+    for i in range(3):
+        for j in range(3):
+            xs = xp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+            xs = xs.reshape(B, Ho, Wo, groups, c)
+            out += np.einsum("bhwgi,gim->bhwgm", xs, k[i, j], optimize=True)
+    return out.reshape(B, Ho, Wo, C)
+
+
+def resnext50(x, w, literal_groups=True):
+    """ResNeXt50, engine/backbone/ResNext.py:180-253,343-354,399-416.  Returns dict of
+    the C1..C5 taps named in BACKBONE_LAYERS['resnext50'] (base.py:147-153)."""
+    eps = 1.001e-5
+    gconv = grouped_conv_literal if literal_groups else grouped_conv_fast
+    taps = {}
+    x = T.conv2d(x, w["conv1_conv/kernel"], None, stride=2, padding=((3, 3), (3, 3)))  # :343-344
+    x = T.relu(_bn(x, w, "conv1_bn", eps))                                            # :347-349
+    taps["C1"] = x
+    x = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))                                   # :351
+    x = T.max_pool(x, 3, 2)                                                           # :352
+
+    def block(x, filters, stride, conv_shortcut, name, groups=32):
+        if conv_shortcut:                                                             # :199-203
+            sc = T.conv2d(x, w[name + "_0_conv/kernel"], None, stride=stride, padding="valid")
+            sc = _bn(sc, w, name + "_0_bn", eps)
+        else:
+            sc = x
+        y = T.conv2d(x, w[name + "_1_conv/kernel"], None, padding="valid")            # :207
+        y = T.relu(_bn(y, w, name + "_1_bn", eps))
+        c = filters // groups
+        y = gconv(y, w[name + "_2_conv/depthwise_kernel"], groups, c, stride)         # :212-219
+        y = T.relu(_bn(y, w, name + "_2_bn", eps))
+        y = T.conv2d(y, w[name + "_3_conv/kernel"], None, padding="valid")            # :225
+        y = _bn(y, w, name + "_3_bn", eps)
+        return T.relu(sc + y)                                                         # :230-231
+
+    def stack(x, filters, blocks, stride1, name):                                     # :235-253
+        x = block(x, filters, stride1, True, name + "_block1")
+        for i in range(2, blocks + 1):
+            x = block(x, filters, 1, False, name + "_block" + str(i))
+        return x
+
+    x = stack(x, 128, 3, 1, "conv2"); taps["C2"] = x                                  # :407-410
+    x = stack(x, 256, 4, 2, "conv3"); taps["C3"] = x
+    x = stack(x, 512, 6, 2, "conv4"); taps["C4"] = x
+    x = stack(x, 1024, 3, 2, "conv5"); taps["C5"] = x
+    return taps
+
+
+MOBILENET_BLOCKS = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2)] + \
+    [(512, 1)] * 5 + [(1024, 2), (1024, 1)]
+
+
+def mobilenet_v1(x, w):
+    """tf.keras.applications.MobileNet(alpha=1.0, include_top=False) -- NOT in the
+    reference tree (call site base.py:253-258, taps :161-167); architecture restated
+    from keras-applications mobilenet.py (parity unpinned):
+    conv1: pad ((0,1),(0,1)) + 3x3 s2 valid, no bias, BN(eps 1e-3), ReLU6; 13 blocks of
+    [dw 3x3 (s2: same one-sided pad + valid; s1: same) + BN + ReLU6 + 1x1 + BN + ReLU6]."""
+    eps = 1e-3
+    taps = {}
+    x = T.conv2d(x, w["conv1/kernel"], None, stride=2, padding=((0, 1), (0, 1)))
+    x = T.relu6(_bn(x, w, "conv1_bn", eps))
+    tapname = {1: "C1", 3: "C2", 5: "C3", 11: "C4", 13: "C5"}
+    for i, (filters, stride) in enumerate(MOBILENET_BLOCKS, start=1):
+        pad = "same" if stride == 1 else ((0, 1), (0, 1))
+        x = T.depthwise_conv2d(x, w["conv_dw_%d/depthwise_kernel" % i], stride=stride, padding=pad)
+        x = T.relu6(_bn(x, w, "conv_dw_%d_bn" % i, eps))
+        x = T.conv2d(x, w["conv_pw_%d/kernel" % i], None, padding="same")
+        x = T.relu6(_bn(x, w, "conv_pw_%d_bn" % i, eps))
+        if i in tapname:
+            taps[tapname[i]] = x
+    return taps
+
+
+PREPROCESS = {  # base.py:190-279
+    "resnext50": dict(rgb=True, mean_shift=True, normalize=2),
+    "mobilenet": dict(rgb=False, mean_shift=False, normalize=2),
+}
+
+
+def backbone_forward(images, w, backbone_type, backbone_outputs, literal_groups=True):
+    """load_backbone graph, engine/backbone/base.py:185-316.  Returns (names, tensors)
+    in the model's output order: C-taps ascending, then P6, P7."""
+    bt = backbone_type.lower()
+    if bt not in PREPROCESS:
+        raise NotImplementedError(bt)
+    x = backbone_preprocess(images, **PREPROCESS[bt])
+    taps = resnext50(x, w, literal_groups) if bt == "resnext50" else mobilenet_v1(x, w)
+    names, feats = [], []
+    for key in ("C1", "C2", "C3", "C4", "C5"):                                        # :287-290
+        if key in backbone_outputs:
+            names.append(key); feats.append(taps[key])
+    last = feats[-1]
+    pad = ((0, 1), (0, 1)) if bt == "mobilenet" else "same"                           # :292-314
+    p6 = T.relu(T.conv2d(last, w["P6_conv/kernel"], w["P6_conv/bias"], stride=2, padding=pad))
+    if "P6" in backbone_outputs:
+        names.append("P6"); feats.append(p6)                                          # pre-norm
+    g6 = T.group_norm(p6, w["P6_norm/gamma"], w["P6_norm/beta"], 32)                  # default groups
+    p7 = T.relu(T.conv2d(g6, w["P7_conv/kernel"], w["P7_conv/bias"], stride=2, padding=pad))
+    if "P7" in backbone_outputs:
+        names.append("P7"); feats.append(p7)
+    return names, feats
+
+
+# =========================================================================== detection head
+def feature_pyramid(inputs, w, strides, prefix="feature_pyramid"):
+    """FeaturePyramid.call, detection.py:51-66: top-down over inputs[::-1]; lateral 1x1
+    (:56); upsample prev (pre-3x3 sum) to lateral size + add (:58-60); 3x3 'P{k}' (:64)."""
+    prev = None
+    outs = []
+    for stride, head in zip(sorted(strides, reverse=True), inputs[::-1]):
+        p = int(np.round(np.log2(stride)))
+        lat = T.conv2d(head, w[f"{prefix}/C{p}_lateral/kernel"], w[f"{prefix}/C{p}_lateral/bias"])
+        if prev is not None:
+            up = T.resize_bilinear_align_corners(prev, lat.shape[1], lat.shape[2])
+            lat = lat + up
+        prev = lat
+        outs.append(T.conv2d(lat, w[f"{prefix}/P{p}/kernel"], w[f"{prefix}/P{p}/bias"]))
+    return outs[::-1]
+
+
+def squeeze_excite(x, w, name):
+    """SqueezeExcite.call, misc.py:42-47: GAP -> Dense(relu,no bias) -> Dense(sigmoid) -> scale."""
+    se = x.mean(axis=(1, 2), dtype=x.dtype)
+    se = T.relu(se @ w[name + "/dense1/kernel"].astype(x.dtype))
+    se = T.sigmoid(se @ w[name + "/dense2/kernel"].astype(x.dtype))
+    return x * se[:, None, None, :]
+
+
+def _tower(x, w, prefix, depth, groups, use_se):
+    for i in range(depth):
+        if use_se:
+            x = squeeze_excite(x, w, f"{prefix}/se{i}")
+        x = T.relu(T.conv2d(x, w[f"{prefix}/conv{i}/kernel"], w[f"{prefix}/conv{i}/bias"]))
+        x = T.group_norm(x, w[f"{prefix}/gn{i}/gamma"], w[f"{prefix}/gn{i}/beta"], groups)
+    return x
+
+
+def classification_subnet(features, w, num_classes, depth, groups, use_se=False,
+                          prefix="classification_sub_net"):
+    """ClassificationSubNet.call, detection.py:204-212 (ctor :162-202): per level own
+    block: depth x [conv3x3+ReLU (:190) ; GN (:194)] ; conv3x3 -> priors*classes + sigmoid
+    (:197-200) ; Reshape((-1,nc)) ; concat axis 1."""
+    heads = []
+    for l, x in enumerate(features):
+        p = f"{prefix}/block{l}"
+        x = _tower(x, w, p, depth, groups, use_se)
+        x = T.sigmoid(T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"]))
+        heads.append(x.reshape(x.shape[0], -1, num_classes))
+    return np.concatenate(heads, axis=1)
+
+
+def box_regression_subnet(features, w, depth, groups, use_se=False,
+                          prefix="box_regression_sub_net"):
+    """BoxRegressionSubNet.call, detection.py:132-140 (ctor :93-130)."""
+    heads = []
+    for l, x in enumerate(features):
+        p = f"{prefix}/block{l}"
+        x = _tower(x, w, p, depth, groups, use_se)
+        x = T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"])
+        heads.append(x.reshape(x.shape[0], -1, 4))
+    return np.concatenate(heads, axis=1)
+
+
+def restore_boxes(loc_pred, pr_boxes):
+    """RestoreBoxes.call, detection.py:325-344 (float32)."""
+    loc = loc_pred.astype(F32)
+    pr = pr_boxes.astype(F32)
+    cx = loc[..., 0] * pr[..., 2] + pr[..., 0]
+    cy = loc[..., 1] * pr[..., 3] + pr[..., 1]
+    bw = np.exp(loc[..., 2]) * pr[..., 2]
+    bh = np.exp(loc[..., 3]) * pr[..., 3]
+    return np.stack([cx, cy, bw, bh], axis=-1).astype(F32)
+
+
+def normalize_boxes(boxes, shape=(1.0, 1.0)):
+    """NormalizeBoxes.call, detection.py:360-375: (cx,cy,w,h) -> (y1,x1,y2,x2)/(H,W);
+    default shape = ones => pixel corners (:362)."""
+    ih, iw = F32(shape[0]), F32(shape[1])
+    b = boxes.astype(F32)
+    cx, cy, bw, bh = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    two = F32(2)
+    x1 = (cx - bw / two) / iw
+    y1 = (cy - bh / two) / ih
+    x2 = (cx + bw / two) / iw
+    y2 = (cy + bh / two) / ih
+    return np.stack([y1, x1, y2, x2], axis=-1).astype(F32)
+
+
+def detection_proposal(cls_pred, boxes, min_confidence, nms_iou_threshold, post_iou_threshold,
+                       nms_max_output_size, max_batch_size=1):
+    """DetectionProposal.call, detection.py:482-567 (+ MoldBatch misc.py:231-286).
+    Returns (molded [B,N,6], flat kept indices [n,3]=(b,a,c) in output order)."""
+    cls_pred = cls_pred.astype(F32)
+    boxes = boxes.astype(F32)
+    B, A, C = cls_pred.shape
+    norm = normalize_boxes(boxes)                                   # :488 (no shape => /1)
+    keep = np.argwhere(cls_pred >= F32(min_confidence)).astype(np.int64)   # :491 row-major
+    conf = cls_pred[keep[:, 0], keep[:, 1], keep[:, 2]]
+    kb = norm[keep[:, 0], keep[:, 1]]
+    ids = keep[:, 0] * (C + 1) + keep[:, 2]                         # :519
+    _, first = np.unique(ids, return_index=True)
+    uniq = ids[np.sort(first)]                                      # tf.unique: first-occurrence order
+    per_class = []
+    for u in uniq:                                                  # :522 map_fn (sequential)
+        ixs = np.nonzero(ids == u)[0]                               # :506
+        sel = T.non_max_suppression(kb[ixs], conf[ixs], nms_max_output_size, nms_iou_threshold)
+        per_class.append(keep[ixs[sel]])                            # :511
+    per_class = np.concatenate(per_class, 0) if per_class else np.zeros((0, 3), np.int64)
+    pc_conf = cls_pred[per_class[:, 0], per_class[:, 1], per_class[:, 2]]
+    pc_box = norm[per_class[:, 0], per_class[:, 1]]
+    final = []
+    for b in range(B):                                              # :552-553
+        ixs = np.nonzero(per_class[:, 0] == b)[0]                   # :541
+        sel = T.non_max_suppression(pc_box[ixs], pc_conf[ixs], nms_max_output_size, post_iou_threshold)
+        final.append(per_class[ixs[sel]])
+    final = np.concatenate(final, 0) if final else np.zeros((0, 3), np.int64)
+    rows = np.concatenate([boxes[final[:, 0], final[:, 1]],                         # :557-563
+                           final[:, 2:3].astype(F32),
+                           cls_pred[final[:, 0], final[:, 1], final[:, 2]][:, None]], axis=1)
+    molded = T.mold_batch(rows.astype(F32), final[:, 0], B)
+    return molded, final
+
+
+# =========================================================================== instance head
+def mask_distribute(proposed, max_k=2, base_size=36):
+    """MaskDistribute.call, instance.py:52-66 (K.epsilon()=1e-7, float32)."""
+    p = proposed.astype(F32)
+    eps = F32(1e-7)
+    size = np.sqrt(p[..., 2] * p[..., 3])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dk = np.log((size + eps) / (F32(base_size) + eps)) / np.log(F32(2.))
+    k = np.clip(np.floor(dk), 0, max_k).astype(F32)
+    k = np.where(p[..., 0] == F32(-1.), p[..., 0], k)
+    return np.concatenate([k[..., None], p], axis=-1)
+
+
+def pyramid_roi_align(fmaps, dist_boxes, image_hw, crop_size=(14, 14)):
+    """PyramidRoiAlign.call, instance.py:109-139: boxes normalised by IMAGE (H,W)
+    (:115-116); per level: idx=where(k==level) row-major (:121); crop_and_resize (:125);
+    MoldBatch both crops and boxes with -1 (:127-134); roi_boxes = concat axis 1 (:135-138)."""
+    B = dist_boxes.shape[0]
+    norm = normalize_boxes(dist_boxes[..., 1:5], shape=image_hw)
+    roi_fmaps, roi_boxes = [], []
+    for level, fmap in enumerate(fmaps):
+        idx = np.argwhere(dist_boxes[..., 0] == level)
+        tb = norm[idx[:, 0], idx[:, 1]]
+        bi = idx[:, 0].astype(np.int32)
+        crops = T.crop_and_resize(fmap, tb, bi, crop_size)
+        roi_fmaps.append(T.mold_batch(crops, bi, B))
+        roi_boxes.append(T.mold_batch(dist_boxes[idx[:, 0], idx[:, 1], 1:], bi, B))
+    roi_boxes = np.concatenate(roi_boxes, axis=1) if len(fmaps) > 1 else roi_boxes[0]
+    return roi_fmaps, roi_boxes
+
+
+def mask_subnet(roi_fmaps, w, depth, groups, use_se=False, prefix="mask_sub_net"):
+    """MaskSubNet.call, instance.py:203-225 (ctor :162-201)."""
+    heads = []
+    for k, x in enumerate(roi_fmaps):
+        B, n = x.shape[:2]
+        p = f"{prefix}/block{k}"
+        x = x.reshape((B * n,) + x.shape[2:])
+        x = _tower(x, w, p, depth, groups, use_se)
+        x = T.relu(T.conv2d_transpose_2x2_s2(x, w[p + "/deconv/kernel"], w[p + "/deconv/bias"]))
+        x = T.sigmoid(T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"]))
+        heads.append(x.reshape((B, n) + x.shape[1:]))
+    return np.concatenate(heads, axis=1) if len(heads) > 1 else heads[0]
+
+
+# =========================================================================== semantic head
+def _gn(x, w, name, groups):
+    return T.group_norm(x, w[name + "/gamma"], w[name + "/beta"], groups)
+
+
+def aspp_network(x, w, atrous_rate=(6, 12, 18), groups=16):
+    """ASPPNetwork.call, semantic.py:139-159; AtrousSeparableConv2D.call :75-83."""
+    b1 = T.relu(_gn(T.conv2d(x, w["aspp_1x1/kernel"]), w, "aspp_1x1_GN", groups))      # :112-116
+    branches = [b1]
+    for r in atrous_rate:                                                               # :63-83
+        y = T.depthwise_conv2d(x, w[f"aspp_{r}_depthwise/depthwise_kernel"], dilation=r)
+        y = T.relu(_gn(y, w, f"aspp_{r}_depthwise_GN", groups))
+        y = T.conv2d(y, w[f"aspp_{r}_pointwise/kernel"])
+        y = T.relu(_gn(y, w, f"aspp_{r}_pointwise_GN", groups))
+        branches.append(y)
+    pool = x.mean(axis=(1, 2), keepdims=True, dtype=x.dtype)                            # :149
+    pool = T.relu(T.conv2d(pool, w["aspp_pool/kernel"]))                                # :126-129 (no GN)
+    pool = T.resize_bilinear_align_corners(pool, x.shape[1], x.shape[2])                # :152
+    cat = np.concatenate(branches + [pool], axis=-1)                                    # :154
+    y = T.conv2d(cat, w["concat_projection/kernel"])
+    return T.relu(_gn(y, w, "concat_projection_GN", groups))                            # :156-157
+
+
+def segmentation_subnet(aspp_out, skip, w, depth, groups, use_se=False,
+                        prefix="segmentation_sub_net"):
+    """SegmentationSubNet.call, semantic.py:221-231 (ctor :183-219)."""
+    s = T.relu(_gn(T.conv2d(skip, w["skip_projection/kernel"]), w, "skip_projection_GN", groups))
+    up = T.resize_bilinear_align_corners(aspp_out, s.shape[1], s.shape[2])              # :226
+    x = np.concatenate([up, s], axis=-1)                                                # :227
+    x = _tower(x, w, prefix, depth, groups, use_se)
+    return T.sigmoid(T.conv2d(x, w[prefix + "/output/kernel"], w[prefix + "/output/bias"]))
+
+
+# =========================================================================== whole path
+def inference_forward(config, weights, images, dtype=np.float32, literal_groups=True,
+                      with_detection=True, with_instance=True, with_semantic=True,
+                      return_internals=False):
+    """construct_inference_network, engine/retinamasklab.py:420-495.
+    Returns [cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred] (subset by flags)."""
+    w = weights
+    x = np.asarray(images).astype(dtype)
+    B, H, W, _ = x.shape
+    names, feats = backbone_forward(x, w, config.backbone.backbone_type,
+                                    config.backbone.backbone_outputs, literal_groups)
+    outs, internals = [], {"backbone": dict(zip(names, feats))}
+    if with_detection:
+        det = config.detection
+        num_classes = len(config.dataset.instance_labels)
+        strides = [2 ** int(n[-1]) for n in config.backbone.backbone_outputs]           # :46-48
+        table = prior_table(strides, [4 * s for s in strides], det.pr_scales, det.pr_ratios)
+        pr = prior_boxes(table, H, W)                                                   # :434
+        fpn_in = [f for n, f in zip(names, feats) if n in det.feature_pyramid_inputs]   # :437-442
+        rest = [f for n, f in zip(names, feats) if n not in det.feature_pyramid_inputs]
+        fpn_strides = [2 ** int(n[1]) for n in det.feature_pyramid_inputs]
+        fouts = feature_pyramid(fpn_in, w, fpn_strides) + rest                          # :443-444
+        internals["features"] = fouts
+        cls_pred = classification_subnet(fouts, w, num_classes, det.num_depth, det.groups,
+                                         det.use_squeeze_excite)
+        loc_pred = box_regression_subnet(fouts, w, det.num_depth, det.groups,
+                                         det.use_separable_conv)   # builder quirk :95
+        outs += [cls_pred, loc_pred]
+        if with_instance:
+            ins = config.instance
+            boxes = restore_boxes(loc_pred, pr[None])                                   # :458
+            proposed, kept = detection_proposal(
+                cls_pred, boxes, det.min_confidence, det.nms_iou_threshold,
+                det.post_iou_threshold, det.nms_max_output_size,
+                config.train.inference_batch_size)                                      # :459-466
+            dist = mask_distribute(proposed, ins.max_k, ins.base_size)                  # :467
+            roi_fmaps, roi_boxes = pyramid_roi_align(fouts[:ins.max_k + 1], dist, (H, W),
+                                                     tuple(ins.crop_size))              # :468-469
+            roi_fmaps = [f.astype(dtype) for f in roi_fmaps]
+            roi_masks = mask_subnet(roi_fmaps, w, ins.num_depth, ins.groups,
+                                    ins.use_squeeze_excite)                             # :470
+            outs += [roi_boxes, roi_masks]
+            internals.update(boxes=boxes, proposed=proposed, kept=kept, dist=dist,
+                             roi_fmaps=roi_fmaps)
+    if with_semantic:
+        sem = config.semantic
+        fmap = dict(zip(names, feats))
+        aspp = aspp_network(fmap[sem.aspp_input_name], w, tuple(sem.atrous_rate), sem.atrous_groups)
+        seg = segmentation_subnet(aspp, fmap[sem.skip_input_name], w, sem.num_depth, sem.groups,
+                                  sem.use_squeeze_excite)
+        internals["aspp"] = aspp
+        outs.append(seg)
+    return (outs, internals) if return_internals else outs
