@@ -1,0 +1,139 @@
+"""GPU parity tests for the detection post-process kernels (index work: bit-exact) and the
+RoI crop; -m gpu."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import masklab as O
+from oracle import tfops as T
+
+RNG = np.random.default_rng(23)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _anchors(H, W):
+    table = O.prior_table([8, 16, 32, 64, 128], [32, 64, 128, 256, 512],
+                          [2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)], [1 / 3, 1 / 2, 1, 2, 3])
+    return O.prior_boxes(table, H, W)
+
+
+def _synthetic_head(B, H, W, C=5, frac=0.01, seed=0):
+    """cls scores with `frac` of entries above 0.5 (no ties), loc deltas ~ N(0, 0.2)."""
+    rng = np.random.default_rng(seed)
+    pri = _anchors(H, W)
+    A = pri.shape[0]
+    cls = rng.uniform(0.0, 0.45, (B, A, C)).astype(np.float32)
+    hot = rng.random((B, A, C)) < frac
+    n_hot = int(hot.sum())
+    # distinct scores by construction (TF leaves the order of equal scores unspecified)
+    cls[hot] = (0.5 + 0.5 * (rng.permutation(n_hot) + 0.5) / max(n_hot, 1)).astype(np.float32)
+    assert len(np.unique(cls[hot])) == n_hot
+    loc = (rng.normal(size=(B, A, 4)) * 0.2).astype(np.float32)
+    return pri, cls, loc
+
+
+def test_restore_boxes():
+    from masklab_hip import ops
+    pri, _, loc = _synthetic_head(2, 128, 128)
+    ref = O.restore_boxes(loc, pri[None])
+    got = host(ops.restore_boxes(dev(loc), dev(pri)))
+    np.testing.assert_allclose(got, ref, rtol=2e-7, atol=1e-5)
+    np.testing.assert_array_equal(got[..., :2], ref[..., :2])      # mul+add, no contraction: exact
+
+
+@pytest.mark.parametrize("B,hw,frac,thr", [(1, (128, 128), 0.01, 0.5), (3, (128, 256), 0.02, 0.5),
+                                           (2, (256, 256), 0.002, 0.5), (2, (128, 128), 0.3, 0.5),
+                                           (2, (128, 128), 0.0, 0.5), (4, (128, 128), 0.01, 0.05)])
+def test_detection_proposal_bit_exact(B, hw, frac, thr):
+    from masklab_hip import ops
+    pri, cls, loc = _synthetic_head(B, hw[0], hw[1], frac=frac, seed=B)
+    if frac == 0.0:
+        cls[1:, :, :] = np.minimum(cls[1:], 0.4)
+        cls[0, 100, 2] = 0.9            # image 0 has one detection, the others none
+    boxes = O.restore_boxes(loc, pri[None])
+    ref, kept_ref = O.detection_proposal(cls, boxes, thr, 0.4, 0.6, 100)
+    prop, counts, kept = ops.detection_proposal(dev(cls), dev(boxes), thr, 0.4, 0.6, 100, want_kept=True)
+    prop, counts, kept = host(prop), host(counts), host(kept)
+    n = max(1, int(counts.max()))
+    assert ref.shape == (B, n, 6)
+    np.testing.assert_array_equal(prop[:, :n], ref)                # rows incl. -1 padding, bit exact
+    assert np.all(prop[:, n:] == -1)
+    for b in range(B):
+        want = kept_ref[kept_ref[:, 0] == b][:, 1:]
+        np.testing.assert_array_equal(kept[b, :counts[b]], want)   # (anchor, class) indices
+        assert np.all(kept[b, counts[b]:] == -1)
+
+
+def test_detection_proposal_tie_break_lower_index():
+    from masklab_hip import ops
+    pri = _anchors(128, 128)
+    A = pri.shape[0]
+    cls = np.zeros((1, A, 5), np.float32)
+    cls[0, [10, 500, 3000], 1] = 0.75          # three equal scores, far apart (no suppression)
+    cls[0, 4000, 3] = 0.75
+    loc = np.zeros((1, A, 4), np.float32)
+    boxes = O.restore_boxes(loc, pri[None])
+    ref, kept_ref = O.detection_proposal(cls, boxes, 0.5, 0.4, 0.6, 100)
+    prop, counts, kept = ops.detection_proposal(dev(cls), dev(boxes), 0.5, 0.4, 0.6, 100, want_kept=True)
+    np.testing.assert_array_equal(host(kept)[0, :host(counts)[0]], kept_ref[:, 1:])
+    np.testing.assert_array_equal(host(prop)[:, :ref.shape[1]], ref)
+
+
+def test_mask_distribute_and_roi_crop():
+    from masklab_hip import ops
+    from masklab_hip.layers import MaskDistribute, PyramidRoiAlign
+    B, H, W = 3, 256, 256
+    rng = np.random.default_rng(5)
+    n_real = [7, 0, 12]
+    cap = 12
+    prop = np.full((B, cap, 6), -1.0, np.float32)
+    for b, n in enumerate(n_real):
+        cx, cy = rng.uniform(20, 236, n), rng.uniform(20, 236, n)
+        w, h = rng.uniform(10, 300, n), rng.uniform(10, 300, n)   # some boxes leave the image
+        prop[b, :n] = np.stack([cx, cy, w, h, rng.integers(0, 5, n), rng.uniform(0.5, 1, n)], 1)
+    fmaps = [rng.normal(size=(B, H // s, W // s, 128)).astype(np.float32) for s in (8, 16, 32)]
+    dist_ref = O.mask_distribute(prop, 2, 36)
+    rf_ref, rb_ref = O.pyramid_roi_align(fmaps, dist_ref, (H, W), (14, 14))
+    dist = MaskDistribute(max_k=2, base_size=36)(dev(prop))
+    np.testing.assert_array_equal(host(dist), dist_ref)
+    roi_fmaps, roi_boxes = PyramidRoiAlign((14, 14))([[dev(f) for f in fmaps], dist, torch.zeros(B, H, W, 3)])
+    np.testing.assert_array_equal(host(roi_boxes), rb_ref)
+    for g, r in zip(roi_fmaps, rf_ref):
+        g = host(g)
+        assert g.shape == r.shape
+        np.testing.assert_array_equal(g == -1.0, r == -1.0)        # MoldBatch padding pattern
+        np.testing.assert_allclose(g, r, atol=2e-5)
+        np.testing.assert_array_equal(g == 0.0, r == 0.0)          # extrapolation cells (in_y<0 etc.)
+    # fused path used by the model: k computed inside from the [B,cap,6] proposals
+    rf2, rb2 = PyramidRoiAlign((14, 14)).crop_levels([dev(f) for f in fmaps], dev(prop), (H, W), has_k=False,
+                                                      base_size=36)
+    np.testing.assert_array_equal(host(rb2), rb_ref)
+    for g, r in zip(rf2, rf_ref):
+        np.testing.assert_allclose(host(g), r, atol=2e-5)
+
+
+def test_prior_layer_matches_oracle():
+    from masklab_hip import PriorBoxes
+    from masklab_hip.layers import PriorLayer
+    pb = PriorBoxes([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)],
+                    [1 / 3, 1 / 2, 1, 2, 3])
+    out = PriorLayer(pb)(torch.zeros(2, 128, 384, 3, device="cuda"))
+    ref = _anchors(128, 384)
+    assert out.shape == (2,) + ref.shape and out.dtype == torch.int32
+    np.testing.assert_array_equal(host(out[1].contiguous()), ref)

@@ -1,0 +1,240 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every C-ABI kernel against the CPU
+oracle on the same seeded inputs.  Tolerances: float outputs 1e-4 abs on O(1) data unless noted
+(the bar for the whole path is 1e-3, BASELINE.json); index outputs bit-exact."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import masklab as O
+from oracle import tfops as T
+
+RNG = np.random.default_rng(11)
+
+
+def rnd(*shape, scale=1.0):
+    return (RNG.normal(size=shape) * scale).astype(np.float32)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from masklab_hip import _lib
+    _lib.check(_lib.load().ml_device_check(), "ml_device_check")
+
+
+def _conv(packed, x, **kw):
+    from masklab_hip import ops
+    return ops.conv2d(dev(x), ops.DeviceConv(packed, "cuda"), **kw)
+
+
+# ------------------------------------------------------------------ conv family
+@pytest.mark.parametrize("k,cin,cout,stride,padding,dil,act,hw", [
+    (1, 64, 256, 1, "valid", 1, "relu", (40, 24)),        # backbone 1x1, N tile 128
+    (3, 128, 128, 1, "same", 1, "relu", (33, 35)),        # tower conv, ragged M
+    (3, 128, 75, 1, "same", 1, "sigmoid", (16, 16)),      # cls output, N tile 32 x3
+    (3, 128, 60, 1, "same", 1, None, (8, 8)),             # loc output, N tile 64
+    (1, 512, 32, 1, "valid", 1, None, (16, 16)),          # skip projection
+    (1, 640, 128, 1, "valid", 1, None, (4, 4)),           # concat projection
+    (3, 2048, 128, 2, "same", 1, "relu", (4, 4)),         # P6 conv (stride 2, same)
+    (3, 128, 128, 2, ((0, 1), (0, 1)), 1, "relu", (7, 9)),  # mobilenet P7 style explicit pad
+    (1, 128, 5, 1, "same", 1, "sigmoid", (28, 28)),       # mask output
+    (1, 256, 512, 2, "valid", 1, None, (16, 16)),         # strided shortcut
+    (3, 160, 128, 1, "same", 1, "relu", (16, 16)),        # decoder conv (cin 160)
+    (1, 8, 128, 1, "valid", 1, "sigmoid", (1, 1)),        # SE dense (cin 8 < 32)
+    (3, 32, 96, 1, "same", 3, "relu6", (12, 12)),         # dilation 3
+])
+def test_conv2d_dense(k, cin, cout, stride, padding, dil, act, hw):
+    from masklab_hip import _lib, packing
+    B = 2
+    x = rnd(B, hw[0], hw[1], cin)
+    w, b = rnd(k, k, cin, cout, scale=1.0 / np.sqrt(k * k * cin)), rnd(cout)
+    ref = T.conv2d(x.astype(np.float64), w, b, stride, padding, dil)
+    ref = {"relu": T.relu, "relu6": T.relu6, "sigmoid": T.sigmoid, None: lambda v: v}[act](ref)
+    got = host(_conv(packing.pack_dense(w, b), x, stride=stride, padding=padding, dilation=dil,
+                     act=_lib.ACT_BY_NAME[act]))
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+
+
+def test_conv2d_residual_and_concat_slice():
+    from masklab_hip import _lib, ops, packing
+    x, res = rnd(2, 12, 12, 64), rnd(2, 12, 12, 96)
+    w, b = rnd(1, 1, 64, 96, scale=0.1), rnd(96)
+    ref = T.relu(T.conv2d(x.astype(np.float64), w, b, padding="valid") + res)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    got = host(ops.conv2d(dev(x), dc, padding="valid", act=_lib.ACT_RELU, residual=dev(res)))
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    buf = torch.full((2, 12, 12, 160), 7.0, device="cuda")
+    ops.conv2d(dev(x), dc, padding="valid", out=buf, out_coff=32)
+    o = host(buf)
+    np.testing.assert_allclose(o[..., 32:128], T.conv2d(x.astype(np.float64), w, b, padding="valid"), atol=2e-5)
+    assert np.all(o[..., :32] == 7.0) and np.all(o[..., 128:] == 7.0)
+
+
+def test_conv2d_out_view_concatenated_prediction():
+    from masklab_hip import ops, packing
+    B, nc, pri = 3, 5, 15
+    levels = [(8, 8), (4, 4)]
+    total = sum(h * w * pri for h, w in levels)
+    pred = torch.zeros((B, total, nc), device="cuda")
+    off, refs = 0, []
+    for (h, w_) in levels:
+        x = rnd(B, h, w_, 32)
+        w, b = rnd(3, 3, 32, pri * nc, scale=0.05), rnd(pri * nc)
+        refs.append(T.conv2d(x.astype(np.float64), w, b).reshape(B, -1, nc))
+        ops.conv2d(dev(x), ops.DeviceConv(packing.pack_dense(w, b), "cuda"),
+                   out_view=(pred, off * nc, pri * nc, total * nc))
+        off += h * w_ * pri
+    np.testing.assert_allclose(host(pred), np.concatenate(refs, 1), atol=2e-5)
+
+
+@pytest.mark.parametrize("k,stride,padding,cout,act", [(7, 2, ((3, 3), (3, 3)), 64, "relu"),
+                                                       (3, 2, ((0, 1), (0, 1)), 32, "relu6")])
+def test_conv2d_rowspan_stem(k, stride, padding, cout, act):
+    from masklab_hip import _lib, packing
+    img = rnd(2, 64, 48, 3)
+    x4 = np.zeros((2, 64, 48, 4), np.float32)
+    x4[..., :3] = img
+    w, b = rnd(k, k, 3, cout, scale=0.2), rnd(cout)
+    ref = {"relu": T.relu, "relu6": T.relu6}[act](T.conv2d(img.astype(np.float64), w, b, stride, padding))
+    got = host(_conv(packing.pack_rowspan(w, b), x4, stride=stride, padding=padding, act=_lib.ACT_BY_NAME[act]))
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,stride,filters", [(4, 1, 128), (8, 2, 256), (16, 1, 512), (32, 2, 1024)])
+def test_conv2d_grouped_resnext(c, stride, filters):
+    from masklab_hip import _lib, packing
+    groups = filters // c
+    x = rnd(2, 10, 12, filters)
+    k = rnd(3, 3, filters, c, scale=1.0 / np.sqrt(9 * c))
+    ref = T.relu(O.grouped_conv_fast(x.astype(np.float64), k, groups, c, stride))
+    got = host(_conv(packing.pack_grouped(k, groups), x, stride=stride, padding=((1, 1), (1, 1)), act=_lib.ACT_RELU))
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+def test_conv2d_transpose2x2():
+    from masklab_hip import _lib, packing
+    x = rnd(5, 14, 14, 128)
+    w, b = rnd(2, 2, 128, 128, scale=0.05), rnd(128)
+    ref = T.relu(T.conv2d_transpose_2x2_s2(x.astype(np.float64), w, b))
+    got = host(_conv(packing.pack_transpose2x2(w, b), x, act=_lib.ACT_RELU))
+    assert got.shape == (5, 28, 28, 128)
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+def test_conv2d_rejects_bad_arguments():
+    from masklab_hip import ops, packing
+    dc = ops.DeviceConv(packing.pack_dense(rnd(1, 1, 64, 8)), "cuda")
+    with pytest.raises(ValueError):
+        ops.conv2d(dev(rnd(1, 4, 4, 32)), dc)                 # too few input channels
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 64), dc)              # host tensor: no CPU fallback
+
+
+# ------------------------------------------------------------------ depthwise / pool / preprocess
+@pytest.mark.parametrize("stride,padding,dil,C,hw", [(1, "same", 1, 64, (20, 20)), (2, ((0, 1), (0, 1)), 1, 128, (16, 18)),
+                                                     (1, "same", 6, 256, (32, 32)), (1, "same", 18, 64, (32, 32)),
+                                                     (1, "same", 12, 32, (8, 8))])
+def test_dwconv3x3(stride, padding, dil, C, hw):
+    from masklab_hip import _lib, ops, packing
+    x = rnd(2, hw[0], hw[1], C)
+    k, b = rnd(3, 3, C, 1, scale=0.3), rnd(C)
+    ref = T.relu6(T.depthwise_conv2d(x.astype(np.float64), k, stride, padding, dil) + b)
+    got = host(ops.dwconv3x3(dev(x), dev(packing.pack_depthwise(k)), dev(b), stride=stride, padding=padding,
+                             dilation=dil, act=_lib.ACT_RELU6))
+    np.testing.assert_allclose(got, ref, atol=1e-5)
+
+
+def test_maxpool3x3s2():
+    from masklab_hip import ops
+    x = np.abs(rnd(2, 17, 20, 64))
+    ref = T.max_pool(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)
+    np.testing.assert_array_equal(host(ops.maxpool3x3s2(dev(x))), ref)
+    xn = rnd(1, 8, 8, 8)          # negative values: the explicit zero pad must win at the border
+    refn = T.max_pool(np.pad(xn, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)
+    np.testing.assert_array_equal(host(ops.maxpool3x3s2(dev(xn))), refn)
+
+
+@pytest.mark.parametrize("bt", ["resnext50", "mobilenet"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_preprocess(bt, dtype):
+    from masklab_hip.backbone import BackBonePreProcess
+    img = RNG.integers(0, 256, (2, 9, 7, 3)).astype(dtype)
+    kw = O.PREPROCESS[bt]
+    ref = O.backbone_preprocess(img.astype(np.float32), **kw)
+    got = host(BackBonePreProcess(**kw)(dev(img)))
+    assert got.shape == (2, 9, 7, 4) and np.all(got[..., 3] == 0)
+    np.testing.assert_allclose(got[..., :3], ref, atol=1e-6)
+
+
+# ------------------------------------------------------------------ GroupNormalization (chunk-norm)
+@pytest.mark.parametrize("shape,G,relu", [((2, 16, 16, 128), 16, False), ((3, 14, 14, 128), 16, False),
+                                          ((2, 32, 32, 32), 16, True), ((2, 2, 2, 128), 32, False),
+                                          ((1, 128, 128, 128), 16, True), ((4, 1, 1, 128), 32, False),
+                                          ((2, 6, 5, 12), 3, False)])
+def test_groupnorm_chunk(shape, G, relu):
+    from masklab_hip import ops
+    x = rnd(*shape) * 3 + 1.5
+    gamma, beta = RNG.uniform(0.5, 1.5, shape[-1]).astype(np.float32), rnd(shape[-1])
+    ref = T.group_norm(x.astype(np.float64), gamma, beta, G)
+    np.testing.assert_allclose(ref, T.group_norm_flat(x, gamma, beta, G), atol=1e-9)
+    if relu:
+        ref = T.relu(ref)
+    got = host(ops.groupnorm_chunk(dev(x), dev(gamma), dev(beta), G, relu=relu))
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    xin = dev(x)
+    ops.groupnorm_chunk(xin, dev(gamma), dev(beta), G, relu=relu, out=xin)      # in place
+    np.testing.assert_allclose(host(xin), ref, atol=2e-5)
+
+
+def test_groupnorm_into_concat_slice_and_large_mean():
+    from masklab_hip import ops
+    x = rnd(2, 8, 8, 32) + 300.0            # mean >> std: the fp64 statistics must not cancel
+    gamma, beta = RNG.uniform(0.5, 1.5, 32).astype(np.float32), rnd(32)
+    ref = T.relu(T.group_norm(x.astype(np.float64), gamma, beta, 16))
+    buf = torch.full((2, 8, 8, 160), -5.0, device="cuda")
+    ops.groupnorm_chunk(dev(x), dev(gamma), dev(beta), 16, relu=True, out=buf, out_coff=128)
+    o = host(buf)
+    np.testing.assert_allclose(o[..., 128:], ref, atol=2e-3)
+    assert np.all(o[..., :128] == -5.0)
+
+
+def test_groupnorm_error_messages():
+    from masklab_hip import GroupNormalization
+    with pytest.raises(ValueError, match="cannot be more than the number of channels"):
+        GroupNormalization(groups=32).build((None, 4, 4, 16))
+    with pytest.raises(ValueError, match="must be a multiple of the number of channels"):
+        GroupNormalization(groups=5).build((None, 4, 4, 16))
+
+
+# ------------------------------------------------------------------ resampling / reductions
+@pytest.mark.parametrize("hw,ohw", [((4, 4), (8, 8)), ((8, 8), (15, 17)), ((1, 1), (16, 16)), ((32, 32), (128, 128)),
+                                    ((5, 7), (5, 7))])
+def test_resize_bilinear_align_corners(hw, ohw):
+    from masklab_hip import ops
+    x, add = rnd(2, hw[0], hw[1], 128), rnd(2, ohw[0], ohw[1], 128)
+    ref = T.resize_bilinear_align_corners(x.astype(np.float64), *ohw)
+    np.testing.assert_allclose(host(ops.resize_bilinear_ac(dev(x), *ohw)), ref, atol=1e-5)
+    lat = dev(add)
+    ops.resize_bilinear_ac(dev(x), *ohw, add=lat, out=lat)           # FPN: in-place add
+    np.testing.assert_allclose(host(lat), ref + add, atol=1e-5)
+
+
+def test_global_mean_and_scale():
+    from masklab_hip import ops
+    x = rnd(3, 9, 11, 2048) + 2
+    np.testing.assert_allclose(host(ops.global_mean(dev(x)))[:, 0, 0], x.astype(np.float64).mean((1, 2)), atol=1e-5)
+    s = rnd(3, 1, 1, 2048)
+    np.testing.assert_allclose(host(ops.scale_channels_(dev(x), dev(s))), x * s, atol=1e-6)
