@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the MaskLab inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one complete hot-path forward (preprocess, backbone, P6/P7,
+FPN, cls/box towers, box decode, DetectionProposal, RoI crop, mask head, ASPP + decoder) over one
+batch of synthetic 1024x1024 RGB images already resident in HBM, plus -- for N>1 -- the RCCL
+all-gather of the fixed-capacity per-GPU detections.  Default workload = BASELINE.json configs[2]
+(ResNeXt-50 full MaskLab, 8 images per GPU; N GPUs process 8*N images = configs[3] at N=8,
+weak scaling).  Weights are random-init of that architecture (no network for checkpoints), with the
+class logits widened so that the NMS and mask head carry their full load (<=100 RoIs / image).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     -- the dominant kernel (MFMA implicit-GEMM conv, 128x128 tile): algorithmic FLOP of
+                  all its launches in one step / their summed duration, timed with HIP events on
+                  the launch stream in an instrumented step; peak = 157.3 TFLOP/s (fp32 MFMA).
+  cpu_baseline -- the NumPy oracle forward ("port", not TF-Keras) timed on the host cores on a
+                  bounded sample (1 image of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "instance-segmentation-road-project_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (backbone, per-GPU batch, H, W, heads)
+    "resnext50_full_b8_1024": ("resnext50", 8, 1024, 1024, "full"),      # BASELINE configs[2]/[3]
+    "mobilenet_fpn_aspp_b1_1024": ("mobilenet", 1, 1024, 1024, "full"),  # BASELINE configs[1] (heads on device too)
+    "mobilenet_full_b1_512": ("mobilenet", 1, 512, 512, "full"),         # BASELINE configs[0] shape
+    "resnext50_full_b2_256": ("resnext50", 2, 256, 256, "full"),         # quick functional check
+}
+
+
+def build_model(backbone, device, seed=0, hot_cls=True):
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = backbone
+    _, model = R.construct_masklab_networks(cfg)
+    w = model.init_weights(seed)
+    if hot_cls:
+        for k in w:
+            if k.startswith("classification_sub_net/") and k.endswith("/output/kernel"):
+                w[k] = (w[k] * 8.0).astype(np.float32)
+    model.load_weights(w, device)
+    return cfg, model, w
+
+
+def cpu_baseline(cfg, weights, H, W, max_seconds=60.0):
+    """Oracle forward on the host (1 image).  Returns dict for the JSON line."""
+    from oracle import masklab as O
+    img = np.random.default_rng(1234).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    O.inference_forward(cfg, weights, img, literal_groups=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle (not TF-Keras), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="resnext50_full_b8_1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from masklab_hip import _lib, ops, parallel
+    _lib.check(_lib.load().ml_device_check(), "ml_device_check")
+    backbone, B, H, W, _heads = WORKLOADS[args.workload]
+    cfg, model, weights = build_model(backbone, device)
+    images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
+
+    def step():
+        outs = model(images)
+        if world > 1:
+            det = model.last_detections
+            parallel.all_gather_detections(det["proposed"], det["counts"])
+        return outs
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    per_kernel = None
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize(device)
+        recs, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for r in recs:
+            a = agg.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += r["start"].elapsed_time(r["end"])
+            a["gflop"] += r["flops"] / 1e9
+            a["mbytes"] += r["bytes"] / 1e6
+        per_kernel = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "gflop": round(v["gflop"], 2),
+                          "mbytes": round(v["mbytes"], 1),
+                          "tflops": round(v["gflop"] / max(v["ms"], 1e-9), 2),
+                          "gbs": round(v["mbytes"] / max(v["ms"], 1e-9), 1)} for k, v in agg.items()}
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        if dom.startswith("conv_mfma"):
+            ach = d["gflop"] / d["ms"]          # GFLOP/ms = TFLOP/s
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                        "algorithmic_gflop_per_step": round(d["gflop"], 2)}
+        else:
+            ach = d["mbytes"] / d["ms"]         # MB/ms = GB/s
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, weights, H, W)
+
+    if rank == 0:
+        det = model.last_detections
+        n_det = det["counts"].cpu().tolist() if det else []
+        total_images = B * world * args.steps
+        line = {
+            "metric": "images/sec at 1024x1024 (MaskLab inference hot path, full forward)",
+            "value": round(total_images / dt, 3),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "backbone": backbone, "per_gpu_batch": B, "global_batch": B * world,
+                       "height": H, "width": W, "parallelism": f"dp{world}",
+                       "weights": "random init (cls logits x8 so NMS / mask head run at full load)",
+                       "detections_per_image_rank0": n_det},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

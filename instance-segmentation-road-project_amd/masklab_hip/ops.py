@@ -15,6 +15,30 @@ from .packing import PackedConv, resolve_padding
 
 _ws_cache = {}
 
+# When set to a list, every launcher appends {"kernel", "flops", "bytes", "start", "end"} with
+# torch.cuda.Event pairs recorded on the launch stream (bench.py's roofline leg).  `bytes` /
+# `flops` are ALGORITHMIC: inputs read once + outputs written once (+ weights once), 2*MACs.
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, kernel, flops, nbytes):
+        self.on = PROFILE is not None
+        if self.on:
+            self.rec = {"kernel": kernel, "flops": float(flops), "bytes": float(nbytes),
+                        "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+
+    def __enter__(self):
+        if self.on:
+            self.rec["start"].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec["end"].record()
+            PROFILE.append(self.rec)
+        return False
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -106,7 +130,13 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
-    _lib.check(lib.ml_conv2d_f32(C.byref(d), _stream()), "ml_conv2d_f32")
+    M = B * Ho * Wo
+    kname = "conv_mfma_128x%d%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile), "_grouped" if p.group_cin_step else "")
+    real_cin = p.span if p.cpp_shift == 30 else 3
+    nbytes = 4 * (B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + M * p.cout + p.cout * p.k_real
+                  + (M * p.cout if residual is not None else 0))
+    with _Prof(kname, 2.0 * M * p.cout * p.k_real, nbytes):
+        _lib.check(lib.ml_conv2d_f32(C.byref(d), _stream()), "ml_conv2d_f32")
     return ret
 
 
@@ -118,9 +148,10 @@ def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_N
     if out is None:
         out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
         out_coff = 0
-    _lib.check(lib.ml_dwconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, Cc, 0,
-                                    out.shape[3], out_coff, Ho, Wo, stride, dilation, pt, pl, act, _stream()),
-               "ml_dwconv3x3_f32")
+    with _Prof("dwconv3x3", 18.0 * B * Ho * Wo * Cc, 4 * (x.numel() + B * Ho * Wo * Cc + 9 * Cc)):
+        _lib.check(lib.ml_dwconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, Cc, 0,
+                                        out.shape[3], out_coff, Ho, Wo, stride, dilation, pt, pl, act, _stream()),
+                   "ml_dwconv3x3_f32")
     return out
 
 
@@ -131,8 +162,9 @@ def maxpool3x3s2(x, pad=1):
     Ho = (H + 2 * pad - 3) // 2 + 1
     Wo = (W + 2 * pad - 3) // 2 + 1
     out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ml_maxpool3x3s2_f32(_ptr(x), _ptr(out), B, H, W, Cc, Ho, Wo, pad, pad, _stream()),
-               "ml_maxpool3x3s2_f32")
+    with _Prof("maxpool3x3s2", 0, 4 * (x.numel() + out.numel())):
+        _lib.check(lib.ml_maxpool3x3s2_f32(_ptr(x), _ptr(out), B, H, W, Cc, Ho, Wo, pad, pad, _stream()),
+                   "ml_maxpool3x3s2_f32")
     return out
 
 
@@ -146,9 +178,10 @@ def preprocess(images, flip, mean, divisor, shift, out_channels=4):
     if ch != 3:
         raise ValueError("images must have 3 channels (RGB, 0..255)")
     out = torch.empty((B, H, W, out_channels), dtype=torch.float32, device=images.device)
-    _lib.check(lib.ml_preprocess_f32(_ptr(images), int(images.dtype == torch.uint8), _ptr(out), B * H * W,
-                                     out_channels, int(flip), float(mean[0]), float(mean[1]), float(mean[2]),
-                                     float(divisor), float(shift), _stream()), "ml_preprocess_f32")
+    with _Prof("preprocess", 0, images.numel() * images.element_size() + 4 * out.numel()):
+        _lib.check(lib.ml_preprocess_f32(_ptr(images), int(images.dtype == torch.uint8), _ptr(out), B * H * W,
+                                         out_channels, int(flip), float(mean[0]), float(mean[1]), float(mean[2]),
+                                         float(divisor), float(shift), _stream()), "ml_preprocess_f32")
     return out
 
 
@@ -170,9 +203,10 @@ def groupnorm_chunk(x, gamma, beta, groups, eps=1e-5, relu=False, out=None, out_
     elif tuple(out.shape[:-1]) != tuple(x.shape[:-1]):
         raise ValueError("groupnorm: concat buffer spatial shape mismatch")
     ws = workspace(lib.ml_groupnorm_workspace_bytes(N, groups), x.device, "gn")
-    _lib.check(lib.ml_groupnorm_chunk_f32(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
-                                          float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()),
-               "ml_groupnorm_chunk_f32")
+    with _Prof("groupnorm_chunk", 0, 8 * x.numel()):
+        _lib.check(lib.ml_groupnorm_chunk_f32(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
+                                              float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()),
+                   "ml_groupnorm_chunk_f32")
     return out
 
 
@@ -184,9 +218,10 @@ def resize_bilinear_ac(x, oh, ow, add=None, out=None, out_coff=0):
         out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device)
         out_coff = 0
     add_cs = add.shape[3] if add is not None else 0
-    _lib.check(lib.ml_resize_bilinear_ac_f32(_ptr(x), _ptr(add), _ptr(out), B, H, W, Cc, Cc, 0, oh, ow,
-                                             add_cs, 0, out.shape[3], out_coff, _stream()),
-               "ml_resize_bilinear_ac_f32")
+    with _Prof("resize_bilinear", 0, 4 * (x.numel() + B * oh * ow * Cc * (2 if add is not None else 1))):
+        _lib.check(lib.ml_resize_bilinear_ac_f32(_ptr(x), _ptr(add), _ptr(out), B, H, W, Cc, Cc, 0, oh, ow,
+                                                 add_cs, 0, out.shape[3], out_coff, _stream()),
+                   "ml_resize_bilinear_ac_f32")
     return out
 
 
@@ -228,9 +263,10 @@ def detection_proposal(cls_pred, boxes, min_confidence, nms_iou, post_iou, max_o
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     kept = torch.empty((B, max_out, 2), dtype=torch.int32, device=dev) if want_kept else None
     ws = workspace(lib.ml_detection_workspace_bytes(B, A, Cn, max_out), dev, "det")
-    _lib.check(lib.ml_detection_proposal_f32(_ptr(cls_pred), _ptr(boxes), _ptr(proposed), _ptr(counts), _ptr(kept),
-                                             B, A, Cn, float(min_confidence), float(nms_iou), float(post_iou),
-                                             int(max_out), _ptr(ws), _stream()), "ml_detection_proposal_f32")
+    with _Prof("detection_proposal", 0, 4 * (cls_pred.numel() + boxes.numel())):
+        _lib.check(lib.ml_detection_proposal_f32(_ptr(cls_pred), _ptr(boxes), _ptr(proposed), _ptr(counts), _ptr(kept),
+                                                 B, A, Cn, float(min_confidence), float(nms_iou), float(post_iou),
+                                                 int(max_out), _ptr(ws), _stream()), "ml_detection_proposal_f32")
     return proposed, counts, kept
 
 

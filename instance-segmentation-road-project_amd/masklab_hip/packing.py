@@ -72,6 +72,7 @@ class PackedConv:
     cin_buffer: int = 0             # channels the input buffer must have (4 for NHWC4 inputs)
     kh_real: int = 1                # real kernel geometry (for padding resolution)
     kw_real: int = 1
+    k_real: int = 0                 # algorithmic MACs per output element (for roofline accounting)
     extra: dict = field(default_factory=dict)
 
 
@@ -106,7 +107,7 @@ def pack_dense(kernel, bias=None, tile=0):
     w2d, n_pad = _pad_rows(w.reshape(cout, kh * kw * span_pad), cout, tile)
     return PackedConv(wgt=w2d, bias=None if bias is None else np.ascontiguousarray(bias, np.float32),
                       KH=kh, KW=kw, span=cin, span_pad=span_pad, cout=cout, n_pad=n_pad, tile=tile,
-                      cin_buffer=cin, kh_real=kh, kw_real=kw)
+                      cin_buffer=cin, kh_real=kh, kw_real=kw, k_real=kh * kw * cin)
 
 
 def pack_rowspan(kernel, bias=None, cpad=4, tile=0):
@@ -123,7 +124,8 @@ def pack_rowspan(kernel, bias=None, cpad=4, tile=0):
     w2d, n_pad = _pad_rows(w.reshape(cout, kh * span_pad), cout, tile)
     return PackedConv(wgt=w2d, bias=None if bias is None else np.ascontiguousarray(bias, np.float32),
                       KH=kh, KW=1, span=span, span_pad=span_pad, cpp_shift=int(math.log2(cpad)),
-                      cout=cout, n_pad=n_pad, tile=tile, cin_buffer=cpad, kh_real=kh, kw_real=kw)
+                      cout=cout, n_pad=n_pad, tile=tile, cin_buffer=cpad, kh_real=kh, kw_real=kw,
+                      k_real=kh * kw * cin)
 
 
 def pack_grouped(dw_kernel, groups, bias=None):
@@ -149,7 +151,7 @@ def pack_grouped(dw_kernel, groups, bias=None):
     assert n_pad == filters or filters % 32
     return PackedConv(wgt=w2d, bias=None if bias is None else np.ascontiguousarray(bias, np.float32),
                       KH=kh, KW=kw, span=32, span_pad=32, cout=filters, n_pad=n_pad, group_cin_step=32,
-                      tile=3, cin_buffer=filters, kh_real=kh, kw_real=kw)
+                      tile=3, cin_buffer=filters, kh_real=kh, kw_real=kw, k_real=kh * kw * c)
 
 
 def grouped_dw_to_dense(dw_kernel, groups):
@@ -175,7 +177,7 @@ def pack_transpose2x2(kernel, bias=None, tile=0):
     w2d, n_pad = _pad_rows(w, 4 * cout, tile)
     return PackedConv(wgt=w2d, bias=None if bias is None else np.ascontiguousarray(bias, np.float32),
                       KH=1, KW=1, span=cin, span_pad=span_pad, cout=4 * cout, n_pad=n_pad, shuffle2x2=1,
-                      tile=tile, cin_buffer=cin)
+                      tile=tile, cin_buffer=cin, k_real=cin)
 
 
 def pack_depthwise(dw_kernel):
