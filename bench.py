@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--workload", default="resnext50_full_b8_1024", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write one line per profiled launch to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +136,12 @@ def main():
         step()
         torch.cuda.synchronize(device)
         recs, ops.PROFILE = ops.PROFILE, None
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                for r in recs:
+                    ms = r["start"].elapsed_time(r["end"])
+                    f.write(f"{r['kernel']:28s} {r.get('shape', ''):60s} {1e3 * ms:9.1f} us "
+                            f"{r['flops'] / 1e9 / max(ms, 1e-9):8.2f} TF/s {r['bytes'] / 1e6 / max(ms, 1e-9):9.1f} GB/s\n")
         agg = {}
         for r in recs:
             a = agg.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0})
@@ -167,6 +174,9 @@ def main():
     if rank == 0:
         det = model.last_detections
         n_det = det["counts"].cpu().tolist() if det else []
+        thr = cfg.detection.min_confidence
+        outs = model(images)
+        n_cand = (outs[0] >= thr).sum(dim=(1, 2)).cpu().tolist() if det else []
         total_images = B * world * args.steps
         line = {
             "metric": "images/sec at 1024x1024 (MaskLab inference hot path, full forward)",
@@ -179,7 +189,7 @@ def main():
             "config": {"workload": args.workload, "backbone": backbone, "per_gpu_batch": B, "global_batch": B * world,
                        "height": H, "width": W, "parallelism": f"dp{world}",
                        "weights": "random init (cls logits x8 so NMS / mask head run at full load)",
-                       "detections_per_image_rank0": n_det},
+                       "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
         }
         print(json.dumps(line))

@@ -11,34 +11,118 @@
 //   Lane (r = lane&31, h = lane>>5) reads 4 consecutive k per ds_read_b128; MFMA step j pairs
 //   k = 8*ks + j (h=0) with k = 8*ks + 4 + j (h=1) -- A and B use the same pairing, so the sum
 //   over K is unchanged.  Result = a k-ordered fp32 fma chain (exact fp32, no reduced precision).
-//   Epilogue: + bias (folded BatchNorm) + optional residual + activation, written to a
-//   channel slice of the destination buffer (concat fusion) or 2x2 pixel-shuffled
-//   (Conv2DTranspose).
+//
+//   Epilogue: the accumulator tile is transposed through LDS (the staging buffers are dead by
+//   then) so every lane owns 4 consecutive output channels of one pixel: bias / residual /
+//   activation run on float4 and a wave stores 2 x 512 contiguous bytes per instruction (the
+//   scalar C/D layout would store 128-byte fragments and serialise the residual loads).
+//   Destinations: a channel slice of a wider buffer (concat fusion), a per-image strided view
+//   (Reshape+Concatenate of the detection heads), or a 2x2 pixel shuffle (Conv2DTranspose).
+//
+//   One launch can carry several independent problems of the same tile shape (the un-shared
+//   head towers run the same conv at 5 pyramid levels: the 4-block P7 problem rides along with
+//   the 1024-block P3 problem instead of being its own latency-bound launch), and a problem with
+//   few tiles but a long K can be split along K: slices write raw partial tiles to a workspace
+//   slab and a second kernel reduces them in a FIXED order (deterministic, no atomics).
 //   Block -> tile map is XCD aware: the NB column tiles that share one 128-pixel A panel get
 //   ids congruent mod 8, i.e. the same XCD / L2.
 #include "common.h"
 
 namespace {
 
-constexpr int LDS_LD = 36;  // floats per staged row (32 + 4 pad)
+constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
+constexpr int MAXP = ML_CONV_MAX_PROBLEMS;
+
+struct Problem {
+    ml_conv2d_desc d;
+    int MB, NB, M, ncpt, ktot;
+    int splits, cps;          // K slices and chunks per slice (splits == 1: direct epilogue)
+    int blocks_per_split;     // 8*ceil(MB/8)*NB
+    float *slab;              // [splits][MB*BM][n_pad] when splits > 1
+};
+
+struct MultiArgs {
+    int n;
+    int start[MAXP + 1];      // prefix sum of blocks per problem
+    Problem p[MAXP];
+};
+
+// ---- shared epilogue math: bias + residual + activation + addressing for 4 consecutive channels
+__device__ __forceinline__ void store_out4(const ml_conv2d_desc &p, int HoWo, int m, int n, f32x4 v, bool vec_ok,
+                                           bool add_residual = true) {
+    const int co = p.shuffle2x2 ? (p.cout >> 2) : p.cout;
+    int ab = 0, o = n;
+    if (p.shuffle2x2) { ab = n / co; o = n - ab * co; }
+    size_t base;
+    if (p.shuffle2x2) {
+        const int b = m / HoWo;
+        const int rr = m - b * HoWo;
+        const int oy = rr / p.Wo;
+        const int ox = rr - oy * p.Wo;
+        base = (((size_t)b * (2 * p.Ho) + 2 * oy + (ab >> 1)) * (size_t)(2 * p.Wo) + 2 * ox + (ab & 1)) * p.out_cstride;
+    } else if (p.out_bstride) {
+        const int b = m / HoWo;
+        base = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * p.out_cstride;
+    } else {
+        base = (size_t)m * p.out_cstride;
+    }
+    base += p.out_coff + o;
+    if (vec_ok) {
+        if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + o);
+        if (p.residual && add_residual)
+            v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], p.act);
+        *reinterpret_cast<f32x4 *>(p.out + base) = r;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.cout) break;
+            float x = v[e];
+            if (p.bias) x += p.bias[o + e];
+            if (p.residual) x += p.residual[(size_t)m * p.res_cstride + p.res_coff + n + e];
+            p.out[base + e] = ml_apply_act(x, p.act);
+        }
+    }
+}
+
+__device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
+    const int co = p.shuffle2x2 ? (p.cout >> 2) : p.cout;
+    bool ok = (co % 4 == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0) && (p.out_bstride % 4 == 0) &&
+              ((((uintptr_t)p.out) & 15) == 0);
+    if (p.bias) ok = ok && ((((uintptr_t)p.bias) & 15) == 0);
+    if (p.residual) ok = ok && (p.res_cstride % 4 == 0) && (p.res_coff % 4 == 0) && ((((uintptr_t)p.residual) & 15) == 0);
+    return ok;
+}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ void __launch_bounds__(256)
-conv_mfma_kernel(const ml_conv2d_desc p, int MB, int NB, int M, int ncpt, int ktot) {
+conv_mfma_kernel(const MultiArgs args) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
     constexpr int B_LD = BN / 32;
     constexpr int BUF = (BM + BN) * LDS_LD;
+    constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
+    static_assert(BM * C_LD <= 2 * BUF, "epilogue tile must fit in the staging buffers");
     extern __shared__ __align__(16) float lds[];
 
-    // ---- XCD-aware tile assignment
-    const int id = blockIdx.x;
+    // ---- which problem / tile / K slice
+    int pi = 0;
+    while (pi + 1 < args.n && (int)blockIdx.x >= args.start[pi + 1]) ++pi;
+    const Problem &P = args.p[pi];
+    const ml_conv2d_desc &p = P.d;
+    int id = blockIdx.x - args.start[pi];
+    const int slice = id / P.blocks_per_split;
+    id -= slice * P.blocks_per_split;
+    const int NB = P.NB, M = P.M, ncpt = P.ncpt, ktot = P.ktot;
+    // XCD-aware tile assignment
     const int xcd = id & 7;
     const int jj = id >> 3;
     const int mt = (jj / NB) * 8 + xcd;
     const int nt = jj % NB;
-    if (mt >= MB) return;
+    if (mt >= P.MB) return;
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
@@ -73,10 +157,39 @@ conv_mfma_kernel(const ml_conv2d_desc p, int MB, int NB, int M, int ncpt, int kt
     const int gofs = p.in_coff + nt * p.group_cin_step;
     const float *wrow = p.wgt + (size_t)(n0 + ld_row) * ktot + ld_c;
 
-    f32x4 areg[A_LD], breg[B_LD];
-    int kh = 0, kw = 0, cc = 0;  // state of the NEXT chunk to load
-    const int nchunks = p.KH * p.KW * ncpt;
+    // chunk range of this K slice
+    const int total_chunks = p.KH * p.KW * ncpt;
+    const int kc_begin = slice * P.cps;
+    const int kc_end = min(kc_begin + P.cps, total_chunks);
+    // state of the NEXT chunk to load: kc -> (kh, kw, cc)
+    int cc = kc_begin % ncpt;
+    const int tap0 = kc_begin / ncpt;
+    int kw = tap0 % p.KW;
+    int kh = tap0 / p.KW;
 
+    // ---- residual tile prefetch: the epilogue's 4-channel x 16-row ownership is known up front, so
+    // the (HBM-latency-bound) residual reads are issued now and fly under the whole K loop.
+    constexpr int V_PER_ROW = BN / 4;               // float4 per tile row
+    constexpr int ROWS_PER_PASS = 256 / V_PER_ROW;  // rows covered by the block per pass
+    constexpr int E_ROWS = BM / ROWS_PER_PASS;      // rows per thread in the epilogue
+    const int c4 = (tid % V_PER_ROW) * 4;
+    const int r0 = tid / V_PER_ROW;
+    const int n = n0 + c4;
+    const bool direct = (P.splits == 1);
+    const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
+    f32x4 res[E_ROWS];
+    const bool pre_res = direct && p.residual && vec_ok;
+    if (pre_res) {
+#pragma unroll
+        for (int i = 0; i < E_ROWS; ++i) {
+            const int m = m0 + r0 + i * ROWS_PER_PASS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M) v = *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+            res[i] = v;
+        }
+    }
+
+    f32x4 areg[A_LD], breg[B_LD];
     auto load_chunk = [&](int kc) {
         const int c = cc * 32 + ld_c;
         const int px = c >> p.cpp_shift;
@@ -97,7 +210,6 @@ conv_mfma_kernel(const ml_conv2d_desc p, int MB, int NB, int M, int ncpt, int kt
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
             breg[i] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * i) * ktot + (size_t)kc * 32);
-        // advance (kh,kw,cc)
         if (++cc == ncpt) {
             cc = 0;
             if (++kw == p.KW) { kw = 0; ++kh; }
@@ -127,13 +239,15 @@ conv_mfma_kernel(const ml_conv2d_desc p, int MB, int NB, int M, int ncpt, int kt
     const int a_off = (wm * TM * 32 + r) * LDS_LD + h * 4;
     const int b_off = BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
 
-    load_chunk(0);
-    store_chunk(0);
+    if (kc_begin < kc_end) {
+        load_chunk(kc_begin);
+        store_chunk(0);
+    }
     __syncthreads();
 
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nchunks) load_chunk(kc + 1);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int buf = (kc - kc_begin) & 1;
+        if (kc + 1 < kc_end) load_chunk(kc + 1);
         const float *base = lds + buf * BUF;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -152,73 +266,61 @@ conv_mfma_kernel(const ml_conv2d_desc p, int MB, int NB, int M, int ncpt, int kt
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
         }
-        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+        if (kc + 1 < kc_end) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int co = p.shuffle2x2 ? (p.cout >> 2) : p.cout;  // channels per output pixel
+    // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Transpose the BM x BN tile through LDS (all staging reads finished at the barrier above).
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn * TN * 32 + ni * 32 + r;
-        if (n >= p.cout) continue;
-        int ab = 0, o = n;
-        if (p.shuffle2x2) { ab = n / co; o = n - ab * co; }
-        const float bv = p.bias ? p.bias[o] : 0.f;
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int m = m0 + wm * TM * 32 + mi * 32 + row;
-                if (m >= M) continue;
-                float v = acc[mi][ni][e] + bv;
-                if (p.residual) v += p.residual[(size_t)m * p.res_cstride + p.res_coff + n];
-                v = ml_apply_act(v, p.act);
-                if (p.shuffle2x2) {
-                    const int b = m / HoWo;
-                    const int rr = m - b * HoWo;
-                    const int oy = rr / p.Wo;
-                    const int ox = rr - oy * p.Wo;
-                    const size_t opix = ((size_t)b * (2 * p.Ho) + 2 * oy + (ab >> 1)) * (size_t)(2 * p.Wo) + 2 * ox + (ab & 1);
-                    p.out[opix * p.out_cstride + p.out_coff + o] = v;
-                } else if (p.out_bstride) {
-                    const int b = m / HoWo;
-                    p.out[(size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * p.out_cstride + p.out_coff + o] = v;
-                } else {
-                    p.out[(size_t)m * p.out_cstride + p.out_coff + o] = v;
-                }
+                const int row = wm * TM * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int col = wn * TN * 32 + ni * 32 + r;
+                lds[row * C_LD + col] = acc[mi][ni][e];
             }
+    __syncthreads();
+
+    if (!direct) {
+        // raw partial tile -> slab[slice][m][n] (n_pad pitch); bias/act happen in the reduce kernel
+        float *slab = P.slab + (size_t)slice * (size_t)(P.MB * BM) * p.n_pad;
+#pragma unroll 4
+        for (int rr = r0; rr < BM; rr += ROWS_PER_PASS) {
+            const int m = m0 + rr;
+            if (m >= M) break;
+            *reinterpret_cast<f32x4 *>(slab + (size_t)m * p.n_pad + n) = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4);
         }
+        return;
+    }
+    if (n >= p.cout) return;
+#pragma unroll
+    for (int i = 0; i < E_ROWS; ++i) {
+        const int rr = r0 + i * ROWS_PER_PASS;
+        const int m = m0 + rr;
+        if (m >= M) break;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4);
+        if (pre_res) v += res[i];
+        store_out4(p, HoWo, m, n, v, vec_ok, !pre_res);
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_conv(const ml_conv2d_desc &d, hipStream_t s) {
-    constexpr int BM = WAVES_M * TM * 32;
-    constexpr int BN = WAVES_N * TN * 32;
-    constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            ml_set_error("conv2d: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
-            return ML_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    const long long M = (long long)d.B * d.Ho * d.Wo;
-    const int MB = (int)((M + BM - 1) / BM);
-    const int NB = d.n_pad / BN;
-    const int ncpt = d.span_pad / 32;
-    const int ktot = d.KH * d.KW * d.span_pad;
-    const long long grid = (long long)((MB + 7) / 8) * 8 * NB;
-    ML_REQUIRE(grid > 0 && grid < (1ll << 31), "conv2d: grid %lld out of range", grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, d, MB, NB, (int)M, ncpt, ktot);
-    ML_CHECK_LAUNCH("conv2d");
-    return ML_OK;
+// out = act(sum_s slab[s] + bias + residual), slices summed in index order (deterministic)
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const ml_conv2d_desc p, const float *__restrict__ slab, int splits, int M, int m_pad) {
+    const int V = p.n_pad / 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * V) return;
+    const int m = (int)(idx / V);
+    const int n = (int)(idx % V) * 4;
+    if (n >= p.cout) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s)
+        v += *reinterpret_cast<const f32x4 *>(slab + ((size_t)s * m_pad + m) * p.n_pad + n);
+    const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
+    store_out4(p, p.Ho * p.Wo, m, n, v, vec_ok);
 }
 
 int pick_tile(int cout, int tile) {
@@ -229,16 +331,7 @@ int pick_tile(int cout, int tile) {
     return 1;
 }
 
-}  // namespace
-
-extern "C" int ml_conv2d_ntile(int32_t cout, int32_t tile) {
-    const int t = pick_tile(cout, tile);
-    return t == 1 ? 128 : (t == 2 ? 64 : 32);
-}
-
-extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {
-    ML_REQUIRE(dp != nullptr, "conv2d: null descriptor");
-    const ml_conv2d_desc &d = *dp;
+int validate(const ml_conv2d_desc &d) {
     ML_REQUIRE(d.in && d.wgt && d.out, "conv2d: null tensor pointer");
     ML_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0, "conv2d: bad spatial dims");
     ML_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0, "conv2d: bad kernel geometry");
@@ -248,14 +341,14 @@ extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {
                "conv2d: input channel stride/offset must be multiples of 4 (16-byte loads)");
     ML_REQUIRE(ml_aligned16(d.in) && ml_aligned16(d.wgt), "conv2d: in/wgt must be 16-byte aligned");
     ML_REQUIRE(d.cpp_shift >= 0 && d.cpp_shift <= 30, "conv2d: bad cpp_shift");
-    ML_REQUIRE(d.cout > 0 && d.out_cstride > 0 && d.out_coff >= 0, "conv2d: bad output channels");
+    ML_REQUIRE(d.cout > 0 && d.out_cstride > 0 && d.out_coff >= 0 && d.out_bstride >= 0, "conv2d: bad output channels");
     ML_REQUIRE((long long)d.B * d.H * d.W < (1ll << 31) / 2, "conv2d: too many input pixels for int32 indexing");
     ML_REQUIRE((long long)d.B * d.Ho * d.Wo < (1ll << 31) - 256, "conv2d: too many output pixels");
     if (d.shuffle2x2) {
         ML_REQUIRE(d.cout % 4 == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Ho == d.H && d.Wo == d.W,
                    "conv2d: shuffle2x2 needs a 1x1 stride-1 problem with cout = 4*Cout");
         ML_REQUIRE(d.out_coff + d.cout / 4 <= d.out_cstride, "conv2d: output slice exceeds buffer channels");
-        ML_REQUIRE(d.residual == nullptr, "conv2d: shuffle2x2 does not take a residual");
+        ML_REQUIRE(d.residual == nullptr && d.out_bstride == 0, "conv2d: shuffle2x2 takes no residual / batch stride");
     } else {
         ML_REQUIRE(d.out_coff + d.cout <= d.out_cstride, "conv2d: output slice exceeds buffer channels");
     }
@@ -272,10 +365,111 @@ extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {
         ML_REQUIRE(d.in_coff + (d.n_pad / 32 - 1) * d.group_cin_step + d.span <= d.in_cstride,
                    "conv2d: grouped input slices exceed buffer channels");
     }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (t) {
-        case 1: return launch_conv<2, 2, 2, 2>(d, s);
-        case 2: return launch_conv<2, 2, 2, 1>(d, s);
-        default: return launch_conv<4, 1, 1, 1>(d, s);
+    return ML_OK;
+}
+
+// split-K heuristic: few tiles and a long K => slice K so that ~2 blocks per CU are in flight
+int choose_splits(long long tiles, int chunks) {
+    if (tiles >= 192 || chunks < 16) return 1;
+    long long want = (512 + tiles - 1) / tiles;
+    int max_by_k = chunks / 8;           // keep >= 8 chunks per slice
+    int s = (int)(want < max_by_k ? want : max_by_k);
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : s;
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 32;
+    constexpr int BN = WAVES_N * TN * 32;
+    constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            ml_set_error("conv2d: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
+            return ML_E_LAUNCH;
+        }
+        attr_set = true;
     }
+    MultiArgs args;
+    args.n = n;
+    long long start = 0, ws_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const ml_conv2d_desc &d = descs[i];
+        Problem &P = args.p[i];
+        P.d = d;
+        const long long M = (long long)d.B * d.Ho * d.Wo;
+        P.M = (int)M;
+        P.MB = (int)((M + BM - 1) / BM);
+        P.NB = d.n_pad / BN;
+        P.ncpt = d.span_pad / 32;
+        P.ktot = d.KH * d.KW * d.span_pad;
+        const int chunks = d.KH * d.KW * P.ncpt;
+        P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
+        int splits = (n == 1 && workspace) ? choose_splits((long long)P.MB * P.NB, chunks) : 1;
+        const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
+        if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
+        P.cps = (chunks + splits - 1) / splits;
+        P.splits = (chunks + P.cps - 1) / P.cps;     // drop empty trailing slices
+        P.slab = nullptr;
+        if (P.splits > 1) {
+            P.slab = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ws_off);
+            ws_off += (slab_bytes + 255) / 256 * 256;
+        } else {
+            P.cps = chunks;
+        }
+        args.start[i] = (int)start;
+        start += (long long)P.blocks_per_split * P.splits;
+        ML_REQUIRE(start < (1ll << 31), "conv2d: grid too large");
+    }
+    args.start[n] = (int)start;
+    hipLaunchKernelGGL(kern, dim3((unsigned)start), dim3(256), LDS_BYTES, s, args);
+    ML_CHECK_LAUNCH("conv2d");
+    for (int i = 0; i < n; ++i) {
+        const Problem &P = args.p[i];
+        if (P.splits > 1) {
+            const long long work = (long long)P.M * (P.d.n_pad / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, P.d, P.slab,
+                               P.splits, P.M, P.MB * BM);
+            ML_CHECK_LAUNCH("conv2d split-K reduce");
+        }
+    }
+    return ML_OK;
+}
+
+}  // namespace
+
+extern "C" int ml_conv2d_ntile(int32_t cout, int32_t tile) {
+    const int t = pick_tile(cout, tile);
+    return t == 1 ? 128 : (t == 2 ? 64 : 32);
+}
+
+extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 64ll << 20; }
+
+extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
+                                   void *stream) {
+    ML_REQUIRE(descs != nullptr && n >= 1 && n <= MAXP, "conv2d: need 1..%d problems", MAXP);
+    int t0 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = validate(descs[i]);
+        if (rc != ML_OK) return rc;
+        const int t = pick_tile(descs[i].cout, descs[i].tile);
+        if (i == 0) t0 = t;
+        ML_REQUIRE(t == t0, "conv2d: all problems of one launch must use the same tile shape");
+    }
+    if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (t0) {
+        case 1: return launch_multi<2, 2, 2, 2>(descs, n, workspace, workspace_bytes, s);
+        case 2: return launch_multi<2, 2, 2, 1>(descs, n, workspace, workspace_bytes, s);
+        default: return launch_multi<4, 1, 1, 1>(descs, n, workspace, workspace_bytes, s);
+    }
+}
+
+extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {
+    ML_REQUIRE(dp != nullptr, "conv2d: null descriptor");
+    return ml_conv2d_multi_f32(dp, 1, nullptr, 0, stream);
 }

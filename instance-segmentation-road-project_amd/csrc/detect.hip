@@ -116,24 +116,55 @@ __global__ void det_init_kernel(DetWs w, int BC) {
     if (i < BC) { w.bucket_count[i] = 0; w.bucket_first[i] = 0x7fffffff; w.s1_count[i] = 0; }
 }
 
-// 1. filtering (detection.py:491-495): one thread per score; survivors appended to their
-//    (image,class) bucket.  Bucket order is irrelevant (keys carry the anchor index).
-__global__ void det_threshold_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, int A,
-                                     int C, float thr, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const float s = cls[i];
-    if (!(s >= thr)) return;
-    const int c = (int)(i % C);
-    const long long ba = i / C;
-    const int a = (int)(ba % A);
-    const int b = (int)(ba / A);
-    const int bucket = b * C + c;
-    const int pos = atomicAdd(&w.bucket_count[bucket], 1);
-    atomicMin(&w.bucket_first[bucket], a * C + c);
-    const long long slot = (long long)bucket * A + pos;
-    w.keys[slot] = ((u64)__float_as_uint(s) << 32) | (u64)(0xffffffffu - (unsigned)a);
-    w.cbox[slot] = corners(*reinterpret_cast<const f32x4 *>(boxes + ba * 4));
+// 1. filtering (detection.py:491-495).  grid (chunks, B): a block scans DET_EPB consecutive scores of
+//    one image.  Survivors are ranked with LDS atomics (one counter per class), then ONE global
+//    atomicAdd per (block, class) reserves the block's range in the bucket -- per-score global
+//    atomics on 5 hot counters serialise (3.8 ms for 13 M scores; this form is HBM-bound).
+//    Bucket order is irrelevant (keys carry the anchor index).
+constexpr int DET_EPT = 8;                 // scores per thread
+constexpr int DET_EPB = 256 * DET_EPT;     // scores per block
+
+__global__ void __launch_bounds__(256)
+det_threshold_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, int A, int C, float thr) {
+    __shared__ int cnt[64], gbase[64], first[64];
+    const int b = blockIdx.y;
+    const long long AC = (long long)A * C;
+    const long long e0 = (long long)blockIdx.x * DET_EPB;
+    if (threadIdx.x < C) { cnt[threadIdx.x] = 0; first[threadIdx.x] = 0x7fffffff; }
+    __syncthreads();
+    float sc[DET_EPT];
+    int pos[DET_EPT];
+#pragma unroll
+    for (int k = 0; k < DET_EPT; ++k) {
+        const long long e = e0 + k * 256 + threadIdx.x;       // (a*C + c) inside image b
+        pos[k] = -1;
+        sc[k] = 0.f;
+        if (e < AC) {
+            const float s = cls[(long long)b * AC + e];
+            if (s >= thr) {
+                const int c = (int)(e % C);
+                sc[k] = s;
+                pos[k] = atomicAdd(&cnt[c], 1);
+                atomicMin(&first[c], (int)e);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C && cnt[threadIdx.x] > 0) {
+        gbase[threadIdx.x] = atomicAdd(&w.bucket_count[b * C + threadIdx.x], cnt[threadIdx.x]);
+        atomicMin(&w.bucket_first[b * C + threadIdx.x], first[threadIdx.x]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DET_EPT; ++k) {
+        if (pos[k] < 0) continue;
+        const long long e = e0 + k * 256 + threadIdx.x;
+        const int c = (int)(e % C);
+        const int a = (int)(e / C);
+        const long long slot = (long long)(b * C + c) * A + gbase[c] + pos[k];
+        w.keys[slot] = ((u64)__float_as_uint(sc[k]) << 32) | (u64)(0xffffffffu - (unsigned)a);
+        w.cbox[slot] = corners(*reinterpret_cast<const f32x4 *>(boxes + ((long long)b * A + a) * 4));
+    }
 }
 
 // 2. per-(image,class) NMS (detection.py:499-524): one block per bucket.
@@ -378,9 +409,9 @@ extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *box
     hipStream_t s = (hipStream_t)stream;
     const int BC = B * C;
     hipLaunchKernelGGL(det_init_kernel, dim3((BC + 255) / 256), dim3(256), 0, s, w, BC);
-    const long long total = (long long)B * A * C;
-    hipLaunchKernelGGL(det_threshold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls_pred, boxes, w, A,
-                       C, min_confidence, total);
+    const long long per_image = (long long)A * C;
+    hipLaunchKernelGGL(det_threshold_kernel, dim3((unsigned)((per_image + DET_EPB - 1) / DET_EPB), B), dim3(256), 0, s,
+                       cls_pred, boxes, w, A, C, min_confidence);
     hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(1024), 0, s, w, A, max_out, nms_iou);
     hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(256), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
                        kept, A, C, max_out, post_iou);

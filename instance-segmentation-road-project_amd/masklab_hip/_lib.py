@@ -43,6 +43,8 @@ SIGNATURES = {
     "ml_device_check": (C.c_int, []),
     "ml_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "ml_conv2d_ntile": (C.c_int, [_i32, _i32]),
+    "ml_conv2d_workspace_bytes": (_i64, []),
+    "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp]),

@@ -84,6 +84,27 @@ class _TowerMixin:
         return x
 
     @staticmethod
+    def _run_towers_multi(blocks, xs):
+        """Depth-major execution of several un-shared towers (one per pyramid level / RoI level):
+        the conv of depth i runs for ALL towers in one multi-problem launch, so the few-tile
+        problems of the coarse levels ride along with the fine level instead of each being a
+        latency-bound launch of its own.  Falls back to tower-major order when a tower holds
+        anything but [Conv2D, GroupNormalization] pairs (SqueezeExcite)."""
+        plain = all(len(b) % 2 == 0 and all(isinstance(b[2 * i], Conv2D) and
+                                              isinstance(b[2 * i + 1], GroupNormalization)
+                                              for i in range(len(b) // 2)) for b in blocks)
+        if not plain or len({len(b) for b in blocks}) != 1:
+            return [_TowerMixin._run_tower(b, x) for b, x in zip(blocks, xs)]
+        xs = list(xs)
+        for i in range(len(blocks[0]) // 2):
+            convs = [b[2 * i] for b in blocks]
+            xs = ops.conv2d_multi([dict(x=x, dc=c.dev, stride=c.strides[0], padding=c.padding,
+                                        dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation])
+                                   for c, x in zip(convs, xs)])
+            xs = [b[2 * i + 1](x, inplace=True) for b, x in zip(blocks, xs)]
+        return xs
+
+    @staticmethod
     def _build_chain(block, shape):
         for layer in block:
             shape = layer.build(shape)
@@ -135,14 +156,16 @@ class BoxRegressionSubNet(Layer, _TowerMixin):
         per_level = [int(x.shape[1]) * int(x.shape[2]) * self.num_priors for x in inputs]
         total = sum(per_level)
         pred = torch.empty((B, total, d), dtype=torch.float32, device=inputs[0].device)
-        off = 0
-        for idx, head in enumerate(inputs):
-            block = self.blocks[idx]
-            x = self._run_tower(block[:-1], head)
-            out_conv = block[-1]
-            ops.conv2d(x, out_conv.dev, stride=1, padding='same', act=ops._lib.ACT_BY_NAME[out_conv.activation],
-                       out_view=(pred, off * d, self.num_priors * d, total * d))
+        blocks = self.blocks[:len(inputs)]
+        xs = self._run_towers_multi([b[:-1] for b in blocks], inputs)
+        problems, off = [], 0
+        for idx, x in enumerate(xs):
+            out_conv = blocks[idx][-1]
+            problems.append(dict(x=x, dc=out_conv.dev, stride=1, padding='same',
+                                 act=ops._lib.ACT_BY_NAME[out_conv.activation],
+                                 out_view=(pred, off * d, self.num_priors * d, total * d)))
             off += per_level[idx]
+        ops.conv2d_multi(problems)
         return pred
 
     def get_config(self):

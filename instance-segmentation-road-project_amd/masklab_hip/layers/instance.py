@@ -110,15 +110,17 @@ class MaskSubNet(Layer, _TowerMixin):
     def call(self, inputs, **kwargs):
         if not isinstance(inputs, list):
             inputs = [inputs]
-        heads = []
-        for idx, head in enumerate(inputs):
-            B, n = head.shape[0], head.shape[1]
-            x = head.reshape((B * n,) + tuple(head.shape[2:]))          # fold rois into the batch (:211-213)
-            block = self.blocks[idx]
-            x = self._run_tower(block[:-2], x)
-            x = block[-2](x)
-            x = block[-1](x)
-            heads.append(x.reshape((B, n) + tuple(x.shape[1:])))
+        from .. import _lib
+        blocks = self.blocks[:len(inputs)]
+        shapes = [(h.shape[0], h.shape[1]) for h in inputs]
+        # fold rois into the batch (:211-213); all levels advance together (multi-problem launches)
+        xs = [h.reshape((h.shape[0] * h.shape[1],) + tuple(h.shape[2:])) for h in inputs]
+        xs = self._run_towers_multi([b[:-2] for b in blocks], xs)
+        xs = ops.conv2d_multi([dict(x=x, dc=b[-2].dev, act=_lib.ACT_BY_NAME[b[-2].activation])
+                               for b, x in zip(blocks, xs)])                    # Conv2DTranspose + ReLU
+        xs = ops.conv2d_multi([dict(x=x, dc=b[-1].dev, stride=1, padding=b[-1].padding,
+                                    act=_lib.ACT_BY_NAME[b[-1].activation]) for b, x in zip(blocks, xs)])
+        heads = [x.reshape((B, n) + tuple(x.shape[1:])) for (B, n), x in zip(shapes, xs)]
         return torch.cat(heads, dim=1) if len(heads) > 1 else heads[0]   # Concatenate(axis=1): data movement
 
     def get_config(self):

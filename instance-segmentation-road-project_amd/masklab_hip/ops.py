@@ -22,10 +22,10 @@ PROFILE = None
 
 
 class _Prof:
-    def __init__(self, kernel, flops, nbytes):
+    def __init__(self, kernel, flops, nbytes, shape=""):
         self.on = PROFILE is not None
         if self.on:
-            self.rec = {"kernel": kernel, "flops": float(flops), "bytes": float(nbytes),
+            self.rec = {"kernel": kernel, "flops": float(flops), "bytes": float(nbytes), "shape": shape,
                         "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
 
     def __enter__(self):
@@ -75,13 +75,9 @@ class DeviceConv:
         self.bias = None if packed.bias is None else torch.from_numpy(packed.bias).to(device)
 
 
-def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
-           residual=None, out=None, out_coff=0, in_coff=0, out_view=None):
-    """ml_conv2d_f32.  `x` [B,H,W,Cbuf]; reads channels [in_coff, in_coff+cin).  Writes into
-    `out[..., out_coff:out_coff+cout]` when given, else allocates.  `out_view=(tensor, elem_off,
-    cstride, bstride)` writes image b's pixels at tensor.data + elem_off + b*bstride with row
-    pitch cstride (used to land a level's head directly in the concatenated prediction)."""
-    lib = _lib.load()
+def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, residual=None, out=None,
+               out_coff=0, in_coff=0, out_view=None):
+    """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args)."""
     p = dc.p
     _require_dev(x, "x")
     B, H, W, Cbuf = x.shape
@@ -94,7 +90,6 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     co = p.cout // 4 if p.shuffle2x2 else p.cout
     oh, ow = (2 * Ho, 2 * Wo) if p.shuffle2x2 else (Ho, Wo)
     d = _lib.ConvDesc()
-    ret = None
     if out_view is not None:
         vt, elem_off, vcs, vbs = out_view
         _require_dev(vt, "out_view")
@@ -103,21 +98,20 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
         if elem_off + (B - 1) * vbs + oh * ow * vcs > vt.numel():
             raise ValueError("conv2d: out_view exceeds the destination tensor")
         ret = vt
-    elif out is None:
-        out = torch.empty((B, oh, ow, co), dtype=torch.float32, device=x.device)
-        out_coff = 0
-    else:
-        _require_dev(out, "out")
-        if tuple(out.shape[:3]) != (B, oh, ow):
-            raise ValueError(f"conv2d: out buffer {tuple(out.shape)} does not match {(B, oh, ow)}")
-    d.in_, d.wgt, d.bias = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
-    if out_view is not None:
         d.out = vt.data_ptr() + 4 * elem_off
         d.out_cstride, d.out_coff, d.out_bstride = vcs, 0, vbs
     else:
+        if out is None:
+            out = torch.empty((B, oh, ow, co), dtype=torch.float32, device=x.device)
+            out_coff = 0
+        else:
+            _require_dev(out, "out")
+            if tuple(out.shape[:3]) != (B, oh, ow):
+                raise ValueError(f"conv2d: out buffer {tuple(out.shape)} does not match {(B, oh, ow)}")
+        ret = out
         d.out = out.data_ptr()
         d.out_cstride, d.out_coff, d.out_bstride = out.shape[3], out_coff, 0
-        ret = out
+    d.in_, d.wgt, d.bias = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
     if residual is not None:
         _require_dev(residual, "residual")
         if tuple(residual.shape[:3]) != (B, Ho, Wo):
@@ -131,13 +125,55 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
     M = B * Ho * Wo
-    kname = "conv_mfma_128x%d%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile), "_grouped" if p.group_cin_step else "")
     real_cin = p.span if p.cpp_shift == 30 else 3
     nbytes = 4 * (B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + M * p.cout + p.cout * p.k_real
                   + (M * p.cout if residual is not None else 0))
-    with _Prof(kname, 2.0 * M * p.cout * p.k_real, nbytes):
-        _lib.check(lib.ml_conv2d_f32(C.byref(d), _stream()), "ml_conv2d_f32")
+    shape = f"M={M} N={p.cout} K={p.KH * p.KW * p.span_pad} k{p.kh_real}x{p.kw_real} s{stride} d{dilation} HxW={H}x{W}"
+    return d, ret, (2.0 * M * p.cout * p.k_real, nbytes, shape)
+
+
+def _conv_kernel_name(p):
+    return "conv_mfma_128x%d%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile), "_grouped" if p.group_cin_step else "")
+
+
+def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
+           residual=None, out=None, out_coff=0, in_coff=0, out_view=None):
+    """ml_conv2d_multi_f32 with one problem (split-K enabled through the shared workspace).
+    `x` [B,H,W,Cbuf]; reads channels [in_coff, in_coff+cin).  Writes into
+    `out[..., out_coff:out_coff+cout]` when given, else allocates.  `out_view=(tensor, elem_off,
+    cstride, bstride)` writes image b's pixels at tensor.data + elem_off + b*bstride with row
+    pitch cstride (used to land a level's head directly in the concatenated prediction)."""
+    lib = _lib.load()
+    d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
+                                                in_coff, out_view)
+    ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
+    with _Prof(_conv_kernel_name(dc.p), flops, nbytes, shape):
+        _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret
+
+
+def conv2d_multi(problems):
+    """One launch for several independent convs of the same tile shape.
+    problems: list of dicts with keys x, dc and the keyword arguments of conv2d().  -> list of results."""
+    lib = _lib.load()
+    n = len(problems)
+    if n == 0:
+        return []
+    if n > 12:
+        return conv2d_multi(problems[:12]) + conv2d_multi(problems[12:])
+    arr = (_lib.ConvDesc * n)()
+    rets, flops, nbytes = [], 0.0, 0.0
+    for i, pr in enumerate(problems):
+        pr = dict(pr)
+        d, ret, (f, nb, _shape) = _conv_desc(pr.pop("x"), pr.pop("dc"), **pr)
+        arr[i] = d
+        rets.append(ret)
+        flops += f
+        nbytes += nb
+    name = _conv_kernel_name(problems[0]["dc"].p)
+    with _Prof(name, flops, nbytes, f"multi x{n}"):
+        _lib.check(lib.ml_conv2d_multi_f32(arr, n, None, 0, _stream()), "ml_conv2d_multi_f32")
+    return rets
 
 
 def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, out=None, out_coff=0):
@@ -203,7 +239,7 @@ def groupnorm_chunk(x, gamma, beta, groups, eps=1e-5, relu=False, out=None, out_
     elif tuple(out.shape[:-1]) != tuple(x.shape[:-1]):
         raise ValueError("groupnorm: concat buffer spatial shape mismatch")
     ws = workspace(lib.ml_groupnorm_workspace_bytes(N, groups), x.device, "gn")
-    with _Prof("groupnorm_chunk", 0, 8 * x.numel()):
+    with _Prof("groupnorm_chunk", 0, 8 * x.numel(), f"N={N} HWC={hwc} G={groups}"):
         _lib.check(lib.ml_groupnorm_chunk_f32(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
                                               float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()),
                    "ml_groupnorm_chunk_f32")

@@ -99,3 +99,46 @@ def test_heads_optional_like_reference():
     (seg,) = model.predict(images)
     (ref,) = O.inference_forward(cfg, w, images, with_detection=False)
     assert float(np.max(np.abs(seg - ref))) <= TOL
+
+
+@pytest.mark.parametrize("case", ["forward_mobilenet_128", "forward_resnext50_128"])
+def test_forward_matches_committed_golden(case, golden_dir):
+    """HIP path vs the committed end-to-end vectors (tests/golden/*.npz): indices bit-exact,
+    float outputs within 1e-3; the oracle is NOT run here."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_forward_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    cfg, model, w, images = mk.build_case(*mk.CASES[case])
+    cfg.detection.min_confidence = float(g["min_confidence"])
+    model.detection_proposal.min_confidence = float(g["min_confidence"])
+    model.load_weights(w, "cuda:0")
+    got = model.predict(images, want_kept=True)
+    det = model.last_detections
+    counts, kept = det["counts"].cpu().numpy(), det["kept"].cpu().numpy()
+    kept_ref = g["kept"]
+    for b in range(images.shape[0]):
+        np.testing.assert_array_equal(kept[b, :counts[b]], kept_ref[kept_ref[:, 0] == b][:, 1:])
+    _check(model, got, [g[n] for n in model.output_names])
+
+
+def test_batch_sharding_equals_full_batch():
+    """data parallel = split the batch, replicate weights, concatenate (reference parallel.py:64-107):
+    per-image results do not depend on which shard an image is in."""
+    from masklab_hip import parallel
+    cfg, model, w = _build("mobilenet", seed=7, hot_cls=True)
+    images = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (4, 128, 128, 3), dtype=np.uint8))
+    model.call(images.cuda())
+    full = {k: v.clone() for k, v in model.last_detections.items() if v is not None}
+    seg_full = model.call(images.cuda())[-1].clone()
+    parts, segs = [], []
+    for r in range(2):
+        outs = model.call(parallel.shard_batch(images, r, 2).cuda())
+        parts.append({k: v.clone() for k, v in model.last_detections.items() if v is not None})
+        segs.append(outs[-1].clone())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([p["counts"] for p in parts]), full["counts"])
+    assert torch.equal(torch.cat([p["proposed"] for p in parts]), full["proposed"])
+    assert torch.equal(torch.cat(segs), seg_full)

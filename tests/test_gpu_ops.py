@@ -134,6 +134,54 @@ def test_conv2d_transpose2x2():
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("k,cin,cout,hw,stride", [(3, 2048, 128, (6, 6), 2), (1, 2048, 128, (16, 16), 1),
+                                                  (1, 2048, 128, (1, 1), 1), (3, 128, 128, (8, 8), 1),
+                                                  (1, 640, 128, (32, 32), 1), (3, 256, 75, (4, 4), 1)])
+def test_conv2d_split_k_small_m(k, cin, cout, hw, stride):
+    """few output tiles + long K => the split-K path (partials in the workspace, fixed-order reduce)."""
+    from masklab_hip import _lib, packing
+    x = rnd(2, hw[0], hw[1], cin)
+    w, b = rnd(k, k, cin, cout, scale=1.0 / np.sqrt(k * k * cin)), rnd(cout)
+    res = None
+    ref = T.conv2d(x.astype(np.float64), w, b, stride, "same")
+    if stride == 1:
+        res = rnd(*ref.shape)
+        ref = ref + res
+    ref = T.relu(ref)
+    from masklab_hip import ops
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    got1 = host(ops.conv2d(dev(x), dc, stride=stride, padding="same", act=_lib.ACT_RELU,
+                           residual=None if res is None else dev(res)))
+    np.testing.assert_allclose(got1, ref, atol=3e-5)
+    got2 = host(ops.conv2d(dev(x), dc, stride=stride, padding="same", act=_lib.ACT_RELU,
+                           residual=None if res is None else dev(res)))
+    np.testing.assert_array_equal(got1, got2)        # deterministic reduction order
+
+
+def test_conv2d_multi_problem_launch():
+    """the same conv shape at 5 pyramid levels + a strided-view destination, one launch"""
+    from masklab_hip import _lib, ops, packing
+    B, nc, pri = 2, 5, 15
+    levels = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    xs = [rnd(B, h, w_, 128) for h, w_ in levels]
+    ws = [(rnd(3, 3, 128, 128, scale=0.03), rnd(128)) for _ in levels]
+    outs = ops.conv2d_multi([dict(x=dev(x), dc=ops.DeviceConv(packing.pack_dense(w, b), "cuda"), act=_lib.ACT_RELU)
+                             for x, (w, b) in zip(xs, ws)])
+    for x, (w, b), o in zip(xs, ws, outs):
+        np.testing.assert_allclose(host(o), T.relu(T.conv2d(x.astype(np.float64), w, b)), atol=2e-5)
+    total = sum(h * w_ * pri for h, w_ in levels)
+    pred = torch.zeros((B, total, nc), device="cuda")
+    wo = [(rnd(3, 3, 128, pri * nc, scale=0.03), rnd(pri * nc)) for _ in levels]
+    probs, off, refs = [], 0, []
+    for x, (w, b), (h, w_) in zip(xs, wo, levels):
+        probs.append(dict(x=dev(x), dc=ops.DeviceConv(packing.pack_dense(w, b), "cuda"), act=_lib.ACT_SIGMOID,
+                          out_view=(pred, off * nc, pri * nc, total * nc)))
+        refs.append(T.sigmoid(T.conv2d(x.astype(np.float64), w, b)).reshape(B, -1, nc))
+        off += h * w_ * pri
+    ops.conv2d_multi(probs)
+    np.testing.assert_allclose(host(pred), np.concatenate(refs, 1), atol=2e-5)
+
+
 def test_conv2d_rejects_bad_arguments():
     from masklab_hip import ops, packing
     dc = ops.DeviceConv(packing.pack_dense(rnd(1, 1, 64, 8)), "cuda")

@@ -1,0 +1,155 @@
+"""CPU tests of the host side: the C ABI loads and exports every declared symbol, the drop-in
+API surface (names, kwargs, get_config, error behaviour) mirrors the reference, weight naming /
+packing is consistent with the oracle, golden fixtures are reproducible."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shared_library_exports_every_header_symbol():
+    from masklab_hip import _lib
+    header = open(os.path.join(ROOT, "include", "masklab_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ml_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in masklab_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.ml_version() == 1
+    assert lib.ml_conv2d_workspace_bytes() > 0 and lib.ml_groupnorm_workspace_bytes(8, 16) > 0
+    assert lib.ml_detection_workspace_bytes(8, 327360, 5, 100) > 8 * 5 * 327360 * 24
+
+
+def test_conv_desc_struct_matches_header_layout():
+    import ctypes
+    from masklab_hip import _lib
+    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 26 * 4 + 8       # 5 pointers, 26 int32, 1 int64
+    assert _lib.ConvDesc.out_bstride.offset == 144
+
+
+def test_product_fails_loudly_without_gpu_tensors():
+    torch = pytest.importorskip("torch")
+    from masklab_hip import ops, packing
+    dc_packed = packing.pack_dense(np.zeros((1, 1, 32, 8), np.float32))
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.conv2d(torch.zeros(1, 4, 4, 32), ops.DeviceConv(dc_packed, "cpu"))     # no CPU fallback
+
+
+def test_model_configuration_matches_reference_defaults_and_roundtrips():
+    from masklab_hip import ModelConfiguration
+    c = ModelConfiguration()
+    assert dir(c) == sorted(["postprocess", "backbone", "detection", "instance", "semantic", "loss", "dataset", "train"])
+    assert c.backbone.backbone_outputs == ('C3', 'C4', 'C5', 'P6', 'P7') and c.backbone.num_features == 128
+    assert c.detection.num_depth == 4 and c.detection.groups == 16 and len(c.detection.pr_scales) == 3
+    assert (c.detection.min_confidence, c.detection.nms_iou_threshold, c.detection.post_iou_threshold,
+            c.detection.nms_max_output_size) == (0.5, 0.4, 0.6, 100)
+    assert (c.instance.max_k, c.instance.base_size, tuple(c.instance.crop_size)) == (2, 36, (14, 14))
+    assert tuple(c.semantic.atrous_rate) == (6, 12, 18) and c.semantic.num_skip_features == 32
+    assert c.train.inference_batch_size == 1 and c.postprocess.resolution == (540, 960)
+    d = c.to_dict()
+    d["detection"]["groups"] = 8
+    c2 = ModelConfiguration()
+    c2.from_dict(d)
+    assert c2.detection.groups == 8 and ModelConfiguration().detection.groups == 16   # no aliasing
+    c2.update("semantic", "num_depth", 2)
+    assert c2.semantic.num_depth == 2
+    ns = c.get_arg_parser(argv=["-detection.groups", "4", "-instance.crop_size", "7", "7"])
+    assert getattr(ns, "detection.groups") == 4 and getattr(ns, "instance.crop_size") == [7, 7]
+
+
+@pytest.mark.parametrize("bt,ntensors", [("resnext50", 569), ("mobilenet", 439)])
+def test_build_api_names_and_weight_specs(bt, ntensors):
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = bt
+    R.K.clear_session()
+    bb = R.build_backbone_network(cfg)
+    assert bb.output_names == ["C3", "C4", "C5", "P6", "P7"]
+    prior, fpn, cls, loc = R.build_detection_network(cfg)
+    restore, dist, roi, mask = R.build_instance_network(cfg)
+    aspp, seg = R.build_semantic_network(cfg)
+    names = [l.name for l in (prior, fpn, cls, loc, restore, dist, roi, mask, aspp, seg)]
+    assert names == ["prior_layer", "feature_pyramid", "classification_sub_net", "box_regression_sub_net",
+                     "restore_boxes", "mask_distribute", "pyramid_roi_align", "mask_sub_net", "aspp_network",
+                     "segmentation_sub_net"]
+    model = R.construct_inference_network(cfg, bb, (prior, fpn, cls, loc), (aspp, seg), (restore, dist, roi, mask))
+    assert model.output_names == ["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"]
+    specs = model.weight_specs()
+    assert len(specs) == ntensors
+    for must in ["P6_conv/kernel", "P6_norm/gamma", "P7_conv/bias", "feature_pyramid/P3/kernel", "aspp_1x1/kernel",
+                 "aspp_6_depthwise/depthwise_kernel", "aspp_18_pointwise_GN/beta", "aspp_pool/kernel",
+                 "concat_projection_GN/gamma", "skip_projection/kernel", "skip_projection_GN/gamma",
+                 "classification_sub_net/block4/output/bias", "mask_sub_net/block2/deconv/kernel"]:
+        assert must in specs, must
+    assert specs["mask_sub_net/block0/deconv/kernel"].shape == (2, 2, 128, 128)
+    assert specs["classification_sub_net/block0/output/kernel"].shape == (3, 3, 128, 75)
+    assert specs["P6_norm/gamma"].shape == (128,)
+    w = model.init_weights(0)
+    np.testing.assert_allclose(w["classification_sub_net/block0/output/bias"], -np.log(99.0), rtol=1e-6)
+    assert np.array_equal(model.init_weights(0)["P6_conv/kernel"], w["P6_conv/kernel"])    # deterministic
+    import re as _re
+    assert R.find_layer_name(_re.compile("^classification_sub_net*"), model) == ["classification_sub_net"]
+    # the reference's regex re-wiring names all resolve (retinamasklab.py:515-586)
+    for pat in ["^prior_layer*", "^feature_pyramid*", "^box_regression_sub_net*", "^restore_boxes*",
+                "^mask_distribute*", "^pyramid_roi_align*", "^mask_sub_net*", "^aspp*", "^segmentation_sub_net*"]:
+        assert len(R.find_layer_name(_re.compile(pat), model)) == 1, pat
+    if bt == "resnext50":
+        assert specs["conv2_block1_2_conv/depthwise_kernel"].shape == (3, 3, 128, 4)
+        assert specs["conv5_block3_3_conv/kernel"].shape == (1, 1, 1024, 2048)
+        assert "conv1_bn/moving_variance" in specs
+    else:
+        assert specs["conv_dw_13/depthwise_kernel"].shape == (3, 3, 1024, 1)
+        assert specs["conv1/kernel"].shape == (3, 3, 3, 32)
+
+
+def test_get_config_mirrors_reference_keys():
+    from masklab_hip import get_custom_objects
+    from masklab_hip.layers import (ClassificationSubNet, DetectionProposal, FeaturePyramid, MaskDistribute,
+                                    PyramidRoiAlign, SegmentationSubNet)
+    from masklab_hip import GroupNormalization
+    assert set(FeaturePyramid([8, 16, 32], 128).get_config()) >= {"strides", "num_features", "name"}
+    cfgd = ClassificationSubNet(5, 5).get_config()
+    assert set(cfgd) >= {"num_blocks", "num_classes", "num_depth", "num_features", "num_priors", "use_separable_conv",
+                         "expand_ratio", "use_squeeze_excite", "squeeze_ratio", "groups"}
+    assert DetectionProposal().get_config()["nms_max_output_size"] == 1000          # reference ctor default
+    assert MaskDistribute().get_config() == {"name": "mask_distribute", "trainable": True, "max_k": 2, "base_size": 64} \
+        or MaskDistribute().get_config()["base_size"] == 64
+    assert PyramidRoiAlign().get_config()["max_batch_size"] == 64
+    assert SegmentationSubNet().get_config()["num_skip_features"] == 48
+    g = GroupNormalization(groups=16).get_config()
+    assert g["groups"] == 16 and g["epsilon"] == 1e-5 and g["axis"] == -1
+    reg = get_custom_objects()
+    for n in ["RestoreBoxes", "PriorLayer", "FeaturePyramid", "ClassificationSubNet", "BoxRegressionSubNet",
+              "MaskSubNet", "DetectionProposal", "MaskDistribute", "PyramidRoiAlign", "ASPPNetwork",
+              "SegmentationSubNet", "GroupNormalization", "BackBonePreProcess", "ResizeLike", "MoldBatch"]:
+        assert n in reg
+
+
+def test_error_behaviour_matches_reference():
+    from masklab_hip import backbone
+    from masklab_hip.layers import PriorLayer
+    with pytest.raises(NotImplementedError):
+        backbone.load_backbone("not_a_backbone")                       # reference base.py:281-282
+    with pytest.raises(ValueError):
+        PriorLayer(prior=[1, 2, 3])                                    # reference detection.py:259
+
+
+def test_forward_golden_is_reproducible_from_seeds(golden_dir):
+    """the committed end-to-end vector really is oracle(init_weights(seed), rng(image_seed))"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_forward_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from oracle import masklab as O
+    g = np.load(os.path.join(golden_dir, "forward_mobilenet_128.npz"))
+    cfg, _model, w, images = mk.build_case(*mk.CASES["forward_mobilenet_128"])
+    cfg.detection.min_confidence = float(g["min_confidence"])
+    outs, internals = O.inference_forward(cfg, w, images, literal_groups=False, return_internals=True)
+    np.testing.assert_array_equal(internals["kept"], g["kept"])
+    for name, o in zip(["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"], outs):
+        np.testing.assert_allclose(o, g[name], rtol=1e-5, atol=1e-5)

@@ -1,0 +1,277 @@
+"""CPU tests of the oracle: the anchor table against the REFERENCE's own output (the only pinned
+fixture), and every restated TF op against an independent formulation (brute-force scalar loops
+or torch-CPU).  See oracle/tfops.py header: parity vs TensorFlow itself is unpinned."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import masklab as O
+from oracle import tfops as T
+
+RNG = np.random.default_rng(3)
+
+
+def rnd(*shape):
+    return RNG.normal(size=shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------ reference-pinned: anchors
+@pytest.mark.parametrize("case", ["default", "three_level", "two_scale", "unsorted_strides"])
+def test_prior_table_matches_reference_output(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "prior_tables.npz"))
+    table = O.prior_table(g[case + "/strides"].tolist(), g[case + "/sizes"].tolist(),
+                          g[case + "/scales"].tolist(), g[case + "/ratios"].tolist())
+    np.testing.assert_array_equal(table, g[case + "/table"])
+    assert len(g[case + "/scales"]) * len(g[case + "/ratios"]) == int(g[case + "/len"])
+    # the product's PriorBoxes is a separate implementation: pin it too
+    from masklab_hip import PriorBoxes
+    pb = PriorBoxes(g[case + "/strides"], g[case + "/sizes"], g[case + "/scales"], g[case + "/ratios"])
+    np.testing.assert_array_equal(pb.table, g[case + "/table"])
+    assert len(pb) == int(g[case + "/len"])
+    np.testing.assert_array_equal(pb.boxes.values, g[case + "/table"])
+
+
+def test_prior_boxes_layout_and_count():
+    table = O.prior_table([8, 16, 32, 64, 128], [32, 64, 128, 256, 512],
+                          [2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)], [1 / 3, 1 / 2, 1, 2, 3])
+    a = O.prior_boxes(table, 1024, 1024)
+    assert a.shape == (327360, 4) and a.dtype == np.int32
+    assert O.prior_boxes(table, 512, 512).shape[0] == 81840
+    # order inside a level: (y, x, anchor); first cell of P3 carries the 15 table rows at (4, 4)
+    np.testing.assert_array_equal(a[:15, :2], np.full((15, 2), 4))
+    np.testing.assert_array_equal(a[:15, 2:], table[:15, 1:])
+    np.testing.assert_array_equal(a[15, :2], [12, 4])                # next cell moves along x
+    from masklab_hip import PriorBoxes
+    pb = PriorBoxes([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)],
+                    [1 / 3, 1 / 2, 1, 2, 3])
+    for hw in [(128, 128), (128, 384), (200, 136)]:
+        np.testing.assert_array_equal(pb.anchors(*hw), O.prior_boxes(table, *hw))
+
+
+# ------------------------------------------------------------------ conv family vs torch CPU
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+def _nchw(x):
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 3, 1, 2))).double()
+
+
+@pytest.mark.parametrize("k,stride,padding,dil", [(3, 1, "same", 1), (3, 2, "same", 1), (1, 2, "valid", 1),
+                                                  (7, 2, ((3, 3), (3, 3)), 1), (3, 2, ((0, 1), (0, 1)), 1),
+                                                  (3, 1, "same", 6)])
+@pytest.mark.parametrize("hw", [(12, 12), (11, 13)])
+def test_conv2d_vs_torch(k, stride, padding, dil, hw):
+    x, w, b = rnd(2, hw[0], hw[1], 5), rnd(k, k, 5, 7), rnd(7)
+    got = T.conv2d(x.astype(np.float64), w, b, stride, padding, dil)
+    Ho, Wo, pt, pb, pl, pr = T._resolve_padding(x, k, k, stride, dil, padding)
+    xp = F.pad(_nchw(x), (pl, pr, pt, pb))
+    ref = F.conv2d(xp, torch.from_numpy(w.transpose(3, 2, 0, 1).copy()).double(), torch.from_numpy(b).double(),
+                   stride=stride, dilation=dil).numpy().transpose(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+
+
+def test_same_padding_is_asymmetric_for_stride_2():
+    assert T.same_pads(16, 3, 2) == (8, 0, 1)        # even: extra pixel after
+    assert T.same_pads(15, 3, 2) == (8, 1, 1)
+    assert T.same_pads(32, 3, 1, 6) == (32, 6, 6)    # dilated: pad = rate
+
+
+def test_depthwise_and_transpose_vs_torch():
+    x, w = rnd(2, 9, 10, 6), rnd(3, 3, 6, 2)
+    got = T.depthwise_conv2d(x.astype(np.float64), w, 1, "same", 2)
+    wt = torch.from_numpy(w.transpose(2, 3, 0, 1).reshape(12, 1, 3, 3).copy()).double()   # out = cin*mult + m
+    ref = F.conv2d(F.pad(_nchw(x), (2, 2, 2, 2)), wt, dilation=2, groups=6).numpy().transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+    xt, wt2, b = rnd(2, 5, 4, 6), rnd(2, 2, 3, 6), rnd(3)
+    got = T.conv2d_transpose_2x2_s2(xt.astype(np.float64), wt2, b)
+    ref = F.conv_transpose2d(_nchw(xt), torch.from_numpy(wt2.transpose(3, 2, 0, 1).copy()).double(),
+                             torch.from_numpy(b).double(), stride=2).numpy().transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+
+
+def test_max_pool_vs_torch():
+    x = np.abs(rnd(2, 11, 12, 4))
+    got = T.max_pool(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)
+    ref = F.max_pool2d(_nchw(x), 3, 2, padding=1).numpy().transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(got, ref)
+
+
+# ------------------------------------------------------------------ GroupNormalization quirk
+@pytest.mark.parametrize("shape,G", [((2, 4, 4, 32), 16), ((1, 14, 14, 128), 16), ((2, 2, 2, 128), 32),
+                                     ((1, 6, 5, 12), 3)])
+def test_group_norm_literal_equals_flat_chunks(shape, G):
+    x = rnd(*shape)
+    gamma, beta = RNG.uniform(0.5, 1.5, shape[-1]).astype(np.float32), rnd(shape[-1])
+    np.testing.assert_allclose(T.group_norm(x.astype(np.float64), gamma, beta, G),
+                               T.group_norm_flat(x, gamma, beta, G), atol=1e-9)
+
+
+def test_group_norm_is_not_channel_grouping():
+    """with axis=-1 on NHWC the reference normalises contiguous chunks of the flat HWC
+    vector -- NOT channel groups.  A textbook GroupNorm gives a different answer."""
+    x = rnd(1, 8, 8, 32)
+    ones, zeros = np.ones(32, np.float32), np.zeros(32, np.float32)
+    ours = T.group_norm(x.astype(np.float64), ones, zeros, 16)
+    textbook = F.group_norm(_nchw(x), 16, eps=1e-5).numpy().transpose(0, 2, 3, 1)
+    assert np.max(np.abs(ours - textbook)) > 0.1
+    # chunk statistics: every contiguous chunk of H*W*C/G elements has mean 0 / var ~1
+    chunks = ours.reshape(1, 16, -1)
+    np.testing.assert_allclose(chunks.mean(-1), 0, atol=1e-9)
+    np.testing.assert_allclose(chunks.var(-1), 1, atol=1e-3)
+
+
+def test_group_norm_errors_match_reference_messages():
+    with pytest.raises(ValueError, match="cannot be more than the number of channels"):
+        T.group_norm(rnd(1, 2, 2, 8), np.ones(8), np.zeros(8), 16)
+    with pytest.raises(ValueError, match="must be a multiple of the number of channels"):
+        T.group_norm(rnd(1, 2, 2, 12), np.ones(12), np.zeros(12), 5)
+
+
+# ------------------------------------------------------------------ resampling vs scalar loops
+def test_resize_bilinear_align_corners_vs_loops():
+    x = rnd(1, 4, 5, 2).astype(np.float64)
+    oh, ow = 9, 7
+    got = T.resize_bilinear_align_corners(x, oh, ow)
+    ref = np.zeros((1, oh, ow, 2))
+    for i in range(oh):
+        sy = np.float32(i) * np.float32((4 - 1) / float(oh - 1))
+        y0, y1, ty = int(math.floor(sy)), min(int(math.ceil(sy)), 3), sy - math.floor(sy)
+        for j in range(ow):
+            sx = np.float32(j) * np.float32((5 - 1) / float(ow - 1))
+            x0, x1, tx = int(math.floor(sx)), min(int(math.ceil(sx)), 4), sx - math.floor(sx)
+            top = x[0, y0, x0] + (x[0, y0, x1] - x[0, y0, x0]) * tx
+            bot = x[0, y1, x0] + (x[0, y1, x1] - x[0, y1, x0]) * tx
+            ref[0, i, j] = top + (bot - top) * ty
+    np.testing.assert_allclose(got, ref, atol=1e-6)
+    np.testing.assert_allclose(got[0, 0, 0], x[0, 0, 0]); np.testing.assert_allclose(got[0, -1, -1], x[0, -1, -1])
+    one = rnd(2, 1, 1, 3).astype(np.float64)                        # 1x1 source = broadcast (ASPP pool)
+    np.testing.assert_allclose(T.resize_bilinear_align_corners(one, 4, 6), np.broadcast_to(one, (2, 4, 6, 3)))
+    same = T.resize_bilinear_align_corners(x, 4, 5)
+    np.testing.assert_allclose(same, x)
+
+
+def test_crop_and_resize_vs_loops_and_extrapolation():
+    img = rnd(2, 6, 7, 3)
+    boxes = np.asarray([[0.1, 0.2, 0.8, 0.9], [-0.2, 0.0, 0.5, 1.3], [0.0, 0.0, 1.0, 1.0], [0.9, 0.9, 0.1, 0.1]],
+                       np.float32)
+    ind = np.asarray([0, 1, 1, 0])
+    got = T.crop_and_resize(img, boxes, ind, (4, 5))
+    H, W = 6, 7
+    for r, (y1, x1, y2, x2) in enumerate(boxes.astype(np.float64)):
+        for i in range(4):
+            iy = y1 * (H - 1) + i * (y2 - y1) * (H - 1) / 3
+            for j in range(5):
+                ix = x1 * (W - 1) + j * (x2 - x1) * (W - 1) / 4
+                if iy < 0 or iy > H - 1 or ix < 0 or ix > W - 1:
+                    want = np.zeros(3)
+                else:
+                    t, b_, l, rr = math.floor(iy), math.ceil(iy), math.floor(ix), math.ceil(ix)
+                    im = img[ind[r]].astype(np.float64)
+                    top = im[t, l] + (im[t, rr] - im[t, l]) * (ix - l)
+                    bot = im[b_, l] + (im[b_, rr] - im[b_, l]) * (ix - l)
+                    want = top + (bot - top) * (iy - t)
+                np.testing.assert_allclose(got[r, i, j], want, atol=2e-5)
+    # full-image box reproduces the corners exactly (normalised by H-1 / W-1 inside the op)
+    np.testing.assert_allclose(got[2, 0, 0], img[1, 0, 0]); np.testing.assert_allclose(got[2, -1, -1], img[1, -1, -1])
+
+
+# ------------------------------------------------------------------ NMS / mold
+def _iou_plain(a, b):
+    ya1, xa1, ya2, xa2 = min(a[0], a[2]), min(a[1], a[3]), max(a[0], a[2]), max(a[1], a[3])
+    yb1, xb1, yb2, xb2 = min(b[0], b[2]), min(b[1], b[3]), max(b[0], b[2]), max(b[1], b[3])
+    aa, ab = (ya2 - ya1) * (xa2 - xa1), (yb2 - yb1) * (xb2 - xb1)
+    if aa <= 0 or ab <= 0:
+        return 0.0
+    inter = max(min(ya2, yb2) - max(ya1, yb1), 0) * max(min(xa2, xb2) - max(xa1, xb1), 0)
+    return inter / (aa + ab - inter)
+
+
+def test_nms_vs_brute_force_and_known_answer():
+    rng = np.random.default_rng(9)
+    c = rng.uniform(0, 50, (60, 2))
+    s = rng.uniform(5, 25, (60, 2))
+    boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+    scores = rng.permutation(60).astype(np.float32) / 60
+    got = T.non_max_suppression(boxes, scores, 10, 0.3)
+    keep = []
+    for i in np.argsort(-scores):
+        if len(keep) == 10:
+            break
+        if all(_iou_plain(boxes[i].astype(np.float64), boxes[k].astype(np.float64)) <= 0.3 for k in keep):
+            keep.append(i)
+    np.testing.assert_array_equal(got, keep)
+    # known answer: two heavy overlaps + one far box; flipped corners tolerated; strict '>' at the threshold
+    b = np.asarray([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60], [10, 10, 0, 0]], np.float32)
+    sc = np.asarray([0.9, 0.8, 0.7, 0.6], np.float32)
+    np.testing.assert_array_equal(T.non_max_suppression(b, sc, 10, 0.5), [0, 2])
+    iou01 = _iou_plain(b[0], b[1])
+    np.testing.assert_array_equal(T.non_max_suppression(b[:2], sc[:2], 10, np.float32(iou01)), [0, 1])
+    np.testing.assert_array_equal(T.non_max_suppression(b, sc, 1, 0.5), [0])
+    # equal scores: lower index first (documented tie rule)
+    np.testing.assert_array_equal(T.non_max_suppression(b[[2, 0]], np.asarray([0.5, 0.5], np.float32), 5, 0.5), [0, 1])
+    # degenerate (zero-area) boxes never suppress each other
+    z = np.asarray([[5, 5, 5, 9], [5, 5, 5, 9]], np.float32)
+    np.testing.assert_array_equal(T.non_max_suppression(z, np.asarray([0.9, 0.8], np.float32), 5, 0.1), [0, 1])
+
+
+def test_mold_batch_edge_cases():
+    rows = np.arange(12, dtype=np.float32).reshape(4, 3)
+    out = T.mold_batch(rows, np.asarray([2, 0, 2, 2]), 3)
+    assert out.shape == (3, 3, 3)
+    np.testing.assert_array_equal(out[0, 0], rows[1]); np.testing.assert_array_equal(out[2, :3], rows[[0, 2, 3]])
+    assert np.all(out[1] == -1) and np.all(out[0, 1:] == -1)
+    empty = T.mold_batch(np.zeros((0, 6), np.float32), np.zeros((0,), np.int64), 2)
+    assert empty.shape == (2, 1, 6) and np.all(empty == -1)           # reference misc.py:236 max(1, .)
+    with pytest.raises(ValueError):
+        T.mold_batch(rows, np.zeros(4, np.int64), 33)                 # 32-slot dynamic_partition
+
+
+def test_detection_proposal_hand_made_case():
+    """two classes, overlapping boxes: per-class NMS, then cross-class NMS, score-descending output"""
+    A, C = 6, 2
+    boxes = np.asarray([[[10, 10, 10, 10], [11, 10, 10, 10], [40, 40, 10, 10],
+                         [10, 10, 10, 10], [70, 70, 8, 8], [41, 40, 10, 10]]], np.float32)   # (cx,cy,w,h)
+    cls = np.zeros((1, A, C), np.float32)
+    cls[0, 0, 0] = 0.9     # kept (best of its cluster, class 0)
+    cls[0, 1, 0] = 0.8     # suppressed by anchor 0 in the per-class NMS (IoU 0.82 > 0.4)
+    cls[0, 2, 0] = 0.7     # kept
+    cls[0, 3, 1] = 0.95    # class 1, identical box to anchor 0 -> wins the cross-class NMS (IoU 1 > 0.6)
+    cls[0, 4, 1] = 0.6     # kept
+    cls[0, 5, 1] = 0.55    # class 1, IoU with anchor 2 = 0.82 > 0.6 -> removed by cross-class NMS
+    out, kept = O.detection_proposal(cls, boxes, 0.5, 0.4, 0.6, 100)
+    np.testing.assert_array_equal(kept, [[0, 3, 1], [0, 2, 0], [0, 4, 1]])
+    assert out.shape == (1, 3, 6)
+    np.testing.assert_allclose(out[0, :, 5], [0.95, 0.7, 0.6])
+    np.testing.assert_array_equal(out[0, :, 4], [1, 0, 1])
+    none, k0 = O.detection_proposal(cls * 0, boxes, 0.5, 0.4, 0.6, 100)
+    assert none.shape == (1, 1, 6) and np.all(none == -1) and len(k0) == 0
+
+
+def test_mask_distribute_levels_and_padding():
+    p = np.full((1, 5, 6), -1.0, np.float32)
+    p[0, 0, :4] = [50, 50, 36, 36]       # size 36 -> k 0
+    p[0, 1, :4] = [50, 50, 72, 72]       # size 72 -> k 1
+    p[0, 2, :4] = [50, 50, 300, 300]     # clipped to max_k
+    p[0, 3, :4] = [50, 50, 10, 10]       # below base -> clipped to 0
+    d = O.mask_distribute(p, 2, 36)
+    np.testing.assert_array_equal(d[0, :, 0], [0, 1, 2, 0, -1])
+    np.testing.assert_array_equal(d[..., 1:], p)
+
+
+def test_grouped_conv_literal_equals_fast():
+    x, k = rnd(1, 6, 7, 32), rnd(3, 3, 32, 4)
+    for stride in (1, 2):
+        np.testing.assert_allclose(O.grouped_conv_literal(x.astype(np.float64), k, 8, 4, stride),
+                                   O.grouped_conv_fast(x.astype(np.float64), k, 8, 4, stride), atol=1e-10)
+
+
+def test_preprocess_modes():
+    img = RNG.integers(0, 256, (1, 2, 2, 3)).astype(np.float32)
+    np.testing.assert_allclose(O.backbone_preprocess(img, rgb=True, mean_shift=True, normalize=2),
+                               (img - np.asarray([123.68, 116.779, 103.939], np.float32)) / 127.5, rtol=1e-6)
+    np.testing.assert_allclose(O.backbone_preprocess(img, rgb=False, mean_shift=False, normalize=2),
+                               img[..., ::-1] / 127.5 - 1, rtol=1e-6)
