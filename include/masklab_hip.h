@@ -86,6 +86,14 @@ int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace,
 /* N-tile width the auto heuristic picks for `cout` (host packs n_pad from it). */
 int ml_conv2d_ntile(int32_t cout, int32_t tile);
 
+/* ResNeXt grouped 3x3 (reference engine/backbone/ResNext.py:212-219: DepthwiseConv2D(depth_multiplier=c)
+ * + SplitGroups/ReduceGroups/MergeGroups), c = channels per group in {4,8,16}, C % 64 == 0, on
+ * v_mfma_f32_4x4x1 (16 independent 4x4 blocks per instruction: no block-diagonal padding waste).
+ * wgt is [C][9][c]: wgt[g*c+m][tap][i] = K[tap][g*c+i][m] (BatchNorm scale folded), bias [C] or NULL. */
+int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo,
+                    int32_t stride, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
+
 /* ---------------------------------------------------------------- depthwise / pooling
  * 3x3 DepthwiseConv2D (depth_multiplier 1), stride 1/2, dilation, explicit pads, +bias
  * (folded BN) +activation.  tf.keras.applications MobileNet body; semantic.py:63; misc.py:85.

@@ -156,6 +156,11 @@ conv_mfma_kernel(const MultiArgs args) {
     }
     const int gofs = p.in_coff + nt * p.group_cin_step;
     const float *wrow = p.wgt + (size_t)(n0 + ld_row) * ktot + ld_c;
+    // hot descriptor fields in registers: the descriptor lives in kernarg memory and would be
+    // re-fetched (s_load + lgkmcnt(0), which also drains LDS) inside the K loop otherwise
+    const int pH = p.H, pW = p.W, pKW = p.KW, pdil = p.dil, pspan = p.span, pshift = p.cpp_shift;
+    const long long pcs = p.in_cstride;
+    const float *pin = p.in;
 
     // chunk range of this K slice
     const int total_chunks = p.KH * p.KW * ncpt;
@@ -192,18 +197,17 @@ conv_mfma_kernel(const MultiArgs args) {
     f32x4 areg[A_LD], breg[B_LD];
     auto load_chunk = [&](int kc) {
         const int c = cc * 32 + ld_c;
-        const int px = c >> p.cpp_shift;
-        const int dy = kh * p.dil, dx = kw * p.dil;
+        const int px = c >> pshift;
+        const int dy = kh * pdil, dx = kw * pdil;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int iy = a_iy0[i] + dy;
             const int ix = a_ix0[i] + dx;
-            const bool ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)(ix + px) < (unsigned)p.W) &&
-                            (c < p.span);
+            const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + px) < (unsigned)pW) && (c < pspan);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                const long long off = (long long)(a_pix[i] + iy * p.W + ix) * (long long)p.in_cstride + gofs + c;
-                v = *reinterpret_cast<const f32x4 *>(p.in + off);
+                const long long off = (long long)(a_pix[i] + iy * pW + ix) * pcs + gofs + c;
+                v = *reinterpret_cast<const f32x4 *>(pin + off);
             }
             areg[i] = v;
         }
@@ -212,7 +216,7 @@ conv_mfma_kernel(const MultiArgs args) {
             breg[i] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * i) * ktot + (size_t)kc * 32);
         if (++cc == ncpt) {
             cc = 0;
-            if (++kw == p.KW) { kw = 0; ++kh; }
+            if (++kw == pKW) { kw = 0; ++kh; }
         }
     };
     auto store_chunk = [&](int buf) {

@@ -1,0 +1,177 @@
+// ResNeXt grouped 3x3 convolution (c = 4/8/16 channels per group) on the 16-block
+// matrix instruction v_mfma_f32_4x4x1_16B_f32.
+//
+// The reference spells this op as DepthwiseConv2D(depth_multiplier=c) + reshape + reduce_sum
+// (engine/backbone/ResNext.py:212-219): out[g*c+m] = sum_{tap,i} x[tap][g*c+i] * K[tap][g*c+i][m].
+// A dense 32x32 MFMA tile wastes 8x (c=4) / 4x (c=8) of its work on the zero blocks of the
+// block-diagonal weight.  The 4x4x1 form runs 16 INDEPENDENT 4x4 outer products per instruction:
+//   block b  <-> 4 consecutive output channels (a quarter/eighth/... of one group)
+//   A[i]     = weight of output channel 4b+i for this (tap, input channel) k-step   (lane 4b+i)
+//   B[j]     = input pixel j of a 4-pixel quad, same k-step, the block's group       (lane 4b+j)
+//   D[i][j]  -> lane 4b+j holds the 4 output channels of pixel j in 4 registers => float4 store.
+// So one instruction yields 64 output channels x 4 pixels with no padding waste for any c = 4q.
+//
+// Block = 256 threads: one spatial tile (TH x TW output pixels) x one 64-channel slab.  The
+// input halo tile is staged in LDS once (pixel stride 80 floats: the four pixels of a quad land
+// on disjoint bank quarters for ds_read_b128) and read 9 times; weights stream from L1/L2 as one
+// float4 per lane per (tap, 4 input channels).  HBM-bound for c = 4, 8 (AI 7-9 flop/B).
+#include "common.h"
+
+namespace {
+
+constexpr int PS = 80;   // LDS floats per input pixel (64 channels + pad, = 16 mod 64)
+constexpr int CS = 64;   // channels per block
+
+template <int STRIDE, int TH, int TW, int CPG>
+__global__ void __launch_bounds__(256)
+gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+                   float *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
+                   int tiles_x) {
+    constexpr int c = CPG;
+    constexpr int THIN = (TH - 1) * STRIDE + 3;
+    constexpr int TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int NPIX = THIN * TWIN;
+    constexpr int NLD = (NPIX + 15) / 16;       // staging float4 loads per thread
+    constexpr int QUADS = TH * TW / 4;          // 4-pixel quads (along x) per tile
+    constexpr int QPW = QUADS / 4;              // quads per wave
+    constexpr int WV = 9 * c / 4;               // weight float4 per lane
+    static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
+    extern __shared__ __align__(16) float tile[];   // [NPIX][PS]
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int blk = lane >> 2;            // 0..15: 4 output channels cs0 + 4*blk + (0..3)
+    const int sub = lane & 3;             // A: output channel within the block; B/D: pixel within the quad
+
+    // ---- all global loads of the block are issued up front (memory-level parallelism): the halo
+    //      tile (16 float4 per pixel, zero outside the image) and this lane's 9*c weights
+    f32x4 stage[NLD];
+    {
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = (tid >> 4) + 16 * i;
+            const int py = p / TWIN, px = p - py * TWIN;
+            const int iy = iy0 + py, ix = ix0 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f32x4 *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+            stage[i] = v;
+        }
+    }
+    f32x4 wv[WV];
+    {
+        const float *wrow = wgt + (long long)(cs0 + blk * 4 + sub) * 9 * c;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) wv[i] = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+    }
+    {
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = (tid >> 4) + 16 * i;
+            if (p < NPIX) *reinterpret_cast<f32x4 *>(tile + p * PS + c4) = stage[i];
+        }
+    }
+    __syncthreads();
+
+    const int gch = ((cs0 + blk * 4) / c) * c - cs0;      // first input channel of the block's group, slab-relative
+    f32x4 acc[QPW];
+    int qbase[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int quad = wave * QPW + q;
+        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
+        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PS + gch;
+    }
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * TWIN + (t % 3)) * PS;
+#pragma unroll
+        for (int i0 = 0; i0 < c; i0 += 4) {
+            const f32x4 w4 = wv[(t * c + i0) / 4];
+            f32x4 xv[QPW];
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) xv[q] = *reinterpret_cast<const f32x4 *>(tile + qbase[q] + toff + i0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < QPW; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4[e], xv[q][e], acc[q], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane (blk, sub) owns pixel `sub` of each quad, output channels cs0+4*blk .. +3
+    const int oc = cs0 + blk * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int quad = wave * QPW + q;
+        const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
+        if (oy >= Ho || ox >= Wo) continue;
+        f32x4 v = acc[q] + bv;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+        *reinterpret_cast<f32x4 *>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc) = r;
+    }
+}
+
+template <int STRIDE, int TH, int TW, int CPG>
+int launch(const float *in, const float *wgt, const float *bias, float *out, int B, int H, int W, int C, int Ho,
+           int Wo, int pad_t, int pad_l, int act, hipStream_t s) {
+    constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int LDS_BYTES = THIN * TWIN * PS * 4;
+    auto kern = gconv_mfma4_kernel<STRIDE, TH, TW, CPG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            ml_set_error("gconv3x3: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
+            return ML_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C,
+                       Ho, Wo, pad_t, pad_l, act, tiles_x);
+    ML_CHECK_LAUNCH("gconv3x3");
+    return ML_OK;
+}
+
+}  // namespace
+
+extern "C" int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out, int32_t B, int32_t H,
+                               int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad_t,
+                               int32_t pad_l, int32_t act, void *stream) {
+    ML_REQUIRE(in && wgt && out, "gconv3x3: null pointer");
+    ML_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "gconv3x3: bad dims");
+    ML_REQUIRE(C > 0 && C % CS == 0 && C / CS < 65536, "gconv3x3: channels must be a multiple of %d", CS);
+    ML_REQUIRE(c == 4 || c == 8 || c == 16, "gconv3x3: channels per group %d must be 4, 8 or 16 (larger groups: "
+               "use ml_conv2d_f32 with group_cin_step)", c);
+    ML_REQUIRE(C % c == 0, "gconv3x3: C must be a multiple of c");
+    ML_REQUIRE(stride == 1 || stride == 2, "gconv3x3: stride must be 1 or 2");
+    ML_REQUIRE(ml_aligned16(in) && ml_aligned16(wgt) && ml_aligned16(out) && (!bias || ml_aligned16(bias)),
+               "gconv3x3: pointers must be 16-byte aligned");
+    ML_REQUIRE((long long)B * H * W < (1ll << 31), "gconv3x3: too many pixels");
+    hipStream_t s = (hipStream_t)stream;
+#define GC_ARGS in, wgt, bias, out, B, H, W, C, Ho, Wo, pad_t, pad_l, act, s
+    if (stride == 1) {
+        if (c == 4) return launch<1, 8, 8, 4>(GC_ARGS);
+        if (c == 8) return launch<1, 8, 8, 8>(GC_ARGS);
+        return launch<1, 8, 8, 16>(GC_ARGS);
+    }
+    if (c == 4) return launch<2, 4, 8, 4>(GC_ARGS);
+    if (c == 8) return launch<2, 4, 8, 8>(GC_ARGS);
+    return launch<2, 4, 8, 16>(GC_ARGS);
+#undef GC_ARGS
+}

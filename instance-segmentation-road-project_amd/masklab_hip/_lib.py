@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmasklab_hip.so")
+# MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
+LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
@@ -45,6 +46,7 @@ SIGNATURES = {
     "ml_conv2d_ntile": (C.c_int, [_i32, _i32]),
     "ml_conv2d_workspace_bytes": (_i64, []),
     "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
+    "ml_gconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp]),

@@ -295,8 +295,32 @@ class GroupedConv2D(Conv2D):
         return k, b
 
     def pack(self, weights):
+        """dense block-diagonal packing for the generic MFMA conv (kept as a cross-check path)"""
         k, b = self.folded(weights)
         return packing.pack_grouped(k, self.groups, b)
+
+    def _load_own(self, weights, device):
+        import torch
+        k, b = self.folded(weights)
+        self.c = self.filters // self.groups
+        # small groups at stride 1 are HBM-bound: the 16-block 4x4x1 MFMA kernel has no padding waste;
+        # c >= 16 (and the four stride-2 convs) run faster on the dense 32-wide MFMA tiles
+        self.use_mfma4 = self.c <= 16 and self.filters % 64 == 0
+        if self.use_mfma4:
+            self.wgt4 = torch.from_numpy(packing.pack_grouped_mfma4(k, self.groups)).to(device)
+            self.bias4 = None if b is None else torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(device)
+            self.dev = True
+        else:
+            self.dev = ops.DeviceConv(packing.pack_grouped(k, self.groups, b), device)
+
+    def call(self, x, **kwargs):
+        if self.dev is None:
+            raise RuntimeError(f"layer '{self.name}' has no weights loaded")
+        if self.use_mfma4:
+            return ops.gconv3x3(x, self.wgt4, self.bias4, self.c, stride=self.strides[0], padding=self.padding,
+                                act=_lib.ACT_BY_NAME[self.activation])
+        return ops.conv2d(x, self.dev, stride=self.strides[0], padding=self.padding,
+                          act=_lib.ACT_BY_NAME[self.activation])
 
 
 class DepthwiseConv2D(Layer):

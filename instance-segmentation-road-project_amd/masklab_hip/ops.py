@@ -176,6 +176,20 @@ def conv2d_multi(problems):
     return rets
 
 
+def gconv3x3(x, wgt, bias, c, stride=1, padding=((1, 1), (1, 1)), act=_lib.ACT_NONE):
+    """ml_gconv3x3_f32: ResNeXt grouped 3x3, wgt [C,9,c] (packing.pack_grouped_mfma4)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    Ho, Wo, pt, pl = resolve_padding(H, W, 3, 3, stride, 1, padding)
+    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    with _Prof("gconv3x3_mfma4", 2.0 * B * Ho * Wo * Cc * 9 * c, 4 * (x.numel() + out.numel() + wgt.numel()),
+               f"M={B * Ho * Wo} C={Cc} c={c} s{stride} HxW={H}x{W}"):
+        _lib.check(lib.ml_gconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, c, Ho, Wo, stride, pt, pl,
+                                       act, _stream()), "ml_gconv3x3_f32")
+    return out
+
+
 def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, out=None, out_coff=0):
     lib = _lib.load()
     _require_dev(x, "x")

@@ -154,6 +154,14 @@ def pack_grouped(dw_kernel, groups, bias=None):
                       tile=3, cin_buffer=filters, kh_real=kh, kw_real=kw, k_real=kh * kw * c)
 
 
+def pack_grouped_mfma4(dw_kernel, groups):
+    """ResNeXt grouped 3x3 for ml_gconv3x3_f32: [C][9][c] with wgt[g*c+m][tap][i] = K[tap][g*c+i][m]."""
+    kh, kw, filters, c = dw_kernel.shape
+    assert (kh, kw) == (3, 3) and filters == groups * c
+    k = dw_kernel.reshape(3, 3, groups, c, c)                 # [kh,kw,g,i,m]
+    return np.ascontiguousarray(np.transpose(k, (2, 4, 0, 1, 3)).reshape(filters, 9, c), np.float32)
+
+
 def grouped_dw_to_dense(dw_kernel, groups):
     """The same re-layout as a plain grouped weight Wg[kh,kw,i,g*c+m] = K[kh,kw,g*c+i,m] (for tests)."""
     kh, kw, filters, c = dw_kernel.shape

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA conv kernel on the shapes that dominate the ResNeXt-50 workload.
+Usage (GPU box): python scripts/conv_bench.py [--reps 20]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instance-segmentation-road-project_amd")]
+import numpy as np
+import torch
+
+from masklab_hip import _lib, ops, packing
+
+# (label, B, H, W, cin, cout, k, stride, residual)
+SHAPES = [
+    ("c2 1x1 64->128", 8, 256, 256, 64, 128, 1, 1, False),
+    ("c2 1x1 64->256 sc", 8, 256, 256, 64, 256, 1, 1, False),
+    ("c2 1x1 128->256 +res", 8, 256, 256, 128, 256, 1, 1, True),
+    ("c2 1x1 256->128", 8, 256, 256, 256, 128, 1, 1, False),
+    ("c3 1x1 256->512 +res", 8, 128, 128, 256, 512, 1, 1, True),
+    ("c3 1x1 512->256", 8, 128, 128, 512, 256, 1, 1, False),
+    ("c4 1x1 512->1024 +res", 8, 64, 64, 512, 1024, 1, 1, True),
+    ("c4 1x1 1024->512", 8, 64, 64, 1024, 512, 1, 1, False),
+    ("c5 1x1 1024->2048 +res", 8, 32, 32, 1024, 2048, 1, 1, True),
+    ("c5 1x1 2048->1024", 8, 32, 32, 2048, 1024, 1, 1, False),
+    ("P3 tower 3x3 128->128", 8, 128, 128, 128, 128, 3, 1, False),
+    ("mask 3x3 128->128 (720 rois)", 720, 14, 14, 128, 128, 3, 1, False),
+    ("decoder 3x3 160->128", 8, 128, 128, 160, 128, 3, 1, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    rng = np.random.default_rng(0)
+    tot_ms, tot_gf = 0.0, 0.0
+    for label, B, H, W, cin, cout, k, stride, res in SHAPES:
+        x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
+        w = rng.normal(size=(k, k, cin, cout)).astype(np.float32) * 0.05
+        dc = ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32)), "cuda")
+        r = torch.from_numpy(rng.normal(size=(B, H // stride, W // stride, cout)).astype(np.float32)).cuda() if res else None
+        out = torch.empty((B, H // stride, W // stride, cout), device="cuda")
+        for _ in range(3):
+            ops.conv2d(x, dc, stride=stride, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+            ops.conv2d(x, dc, stride=stride, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / args.reps
+        gf = 2.0 * out.numel() * k * k * cin / 1e9
+        mb = 4 * (x.numel() + out.numel() * (2 if res else 1)) / 1e6
+        tot_ms += ms
+        tot_gf += gf
+        print(f"{label:32s} {1e3 * ms:8.1f} us {gf / ms:7.1f} TF/s {mb / ms:8.0f} GB/s")
+    print(f"{'TOTAL':32s} {1e3 * tot_ms:8.1f} us {tot_gf / tot_ms:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,23 @@ def test_conv2d_grouped_resnext(c, stride, filters):
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("c,stride,filters,hw", [(4, 1, 128, (16, 16)), (4, 1, 128, (13, 21)), (8, 1, 256, (10, 12)),
+                                                  (8, 2, 256, (16, 24)), (16, 1, 512, (9, 9)), (16, 2, 512, (8, 8)),
+                                                  (4, 2, 128, (31, 17)), (8, 1, 64, (8, 8))])
+def test_gconv3x3_mfma4(c, stride, filters, hw):
+    """dedicated grouped 3x3 (v_mfma_f32_4x4x1 16-block form) vs the reference's literal spelling"""
+    from masklab_hip import _lib, ops, packing
+    groups = filters // c
+    x = rnd(2, hw[0], hw[1], filters)
+    k = rnd(3, 3, filters, c, scale=1.0 / np.sqrt(9 * c))
+    b = rnd(filters)
+    ref = T.relu(O.grouped_conv_fast(x.astype(np.float64), k, groups, c, stride) + b)
+    got = host(ops.gconv3x3(dev(x), dev(packing.pack_grouped_mfma4(k, groups)), dev(b), c, stride=stride,
+                            act=_lib.ACT_RELU))
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
 def test_conv2d_transpose2x2():
     from masklab_hip import _lib, packing
     x = rnd(5, 14, 14, 128)
