@@ -178,6 +178,9 @@ int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int32_t row_str
                            int32_t level, int32_t n_l, int32_t ch, int32_t cw,
                            float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);
 
+/* x += y over n floats (n % 4 == 0): the `Add` of MobileSeparableConv2D (misc.py:92,105) */
+int ml_add_f32(float *x, const float *y, int64_t n, void *stream);
+
 /* fill n floats with v */
 int ml_fill_f32(float *x, float v, int64_t n, void *stream);
 

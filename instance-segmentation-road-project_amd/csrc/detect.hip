@@ -168,36 +168,79 @@ det_threshold_kernel(const float *__restrict__ cls, const float *__restrict__ bo
 }
 
 // 2. per-(image,class) NMS (detection.py:499-524): one block per bucket.
-__global__ void __launch_bounds__(1024)
+//    Keys live in registers (NMS_R per thread, slot = r*512 + tid) when the bucket fits, so a
+//    round is: register max -> block max -> owner publishes the winner's box -> kill sweep whose
+//    box loads are issued in independent batches (the sweep is latency-, not bandwidth-bound).
+//    Buckets larger than 1024*NMS_R fall back to keys in global memory.
+constexpr int NMS_T = 512;
+constexpr int NMS_R = 48;
+
+__global__ void __launch_bounds__(NMS_T)
 det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr) {
     __shared__ u64 red[17];
-    __shared__ int sel_slot;
+    __shared__ f32x4 sel_box;
     const int bucket = blockIdx.x;
     const int n = w.bucket_count[bucket];
     u64 *keys = w.keys + (long long)bucket * A;
     const f32x4 *cb = w.cbox + (long long)bucket * A;
     int picked = 0;
-    for (; picked < max_out; ++picked) {
-        u64 best = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const u64 k = keys[i];
-            best = k > best ? k : best;
+    if (n <= NMS_T * NMS_R) {
+        u64 k[NMS_R];
+#pragma unroll
+        for (int r = 0; r < NMS_R; ++r) {
+            const int i = r * NMS_T + threadIdx.x;
+            k[r] = i < n ? keys[i] : 0;
         }
-        best = block_max_u64(best, red);
-        if (best == 0) break;  // uniform: nothing alive
-        const unsigned a_sel = 0xffffffffu - (unsigned)(best & 0xffffffffu);
-        // locate the selected candidate's box: the owner publishes its slot
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if (keys[i] == best) sel_slot = i;
-        __syncthreads();
-        const f32x4 sb = cb[sel_slot];
-        if (threadIdx.x == 0) w.s1_anchor[(long long)bucket * max_out + picked] = (int)a_sel;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const u64 k = keys[i];
-            if (k == 0) continue;
-            if (i == sel_slot || iou_tf(cb[i], sb) > iou_thr) keys[i] = 0;
+        for (; picked < max_out; ++picked) {
+            u64 best = 0;
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r) best = k[r] > best ? k[r] : best;
+            best = block_max_u64(best, red);
+            if (best == 0) break;  // uniform: nothing alive
+#pragma unroll
+            for (int r = 0; r < NMS_R; ++r)
+                if (k[r] == best) { sel_box = cb[r * NMS_T + threadIdx.x]; k[r] = 0; }
+            __syncthreads();
+            const f32x4 sb = sel_box;
+            if (threadIdx.x == 0)
+                w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+#pragma unroll
+            for (int r0 = 0; r0 < NMS_R; r0 += 8) {
+                if (r0 * NMS_T >= n) break;                       // uniform
+                f32x4 bx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                     // 8 independent loads in flight
+                    const int i = (r0 + u) * NMS_T + threadIdx.x;
+                    bx[u] = (k[r0 + u] != 0) ? cb[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k[r0 + u] != 0 && iou_tf(bx[u], sb) > iou_thr) k[r0 + u] = 0;
+            }
         }
-        __syncthreads();
+    } else {
+        __shared__ int sel_slot;
+        for (; picked < max_out; ++picked) {
+            u64 best = 0;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const u64 kk = keys[i];
+                best = kk > best ? kk : best;
+            }
+            best = block_max_u64(best, red);
+            if (best == 0) break;
+            for (int i = threadIdx.x; i < n; i += blockDim.x)
+                if (keys[i] == best) sel_slot = i;
+            __syncthreads();
+            const f32x4 sb = cb[sel_slot];
+            if (threadIdx.x == 0)
+                w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const u64 kk = keys[i];
+                if (kk == 0) continue;
+                if (i == sel_slot || iou_tf(cb[i], sb) > iou_thr) keys[i] = 0;
+            }
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) w.s1_count[bucket] = picked;
 }
@@ -412,7 +455,7 @@ extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *box
     const long long per_image = (long long)A * C;
     hipLaunchKernelGGL(det_threshold_kernel, dim3((unsigned)((per_image + DET_EPB - 1) / DET_EPB), B), dim3(256), 0, s,
                        cls_pred, boxes, w, A, C, min_confidence);
-    hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(1024), 0, s, w, A, max_out, nms_iou);
+    hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(NMS_T), 0, s, w, A, max_out, nms_iou);
     hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(256), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
                        kept, A, C, max_out, post_iou);
     ML_CHECK_LAUNCH("detection_proposal");

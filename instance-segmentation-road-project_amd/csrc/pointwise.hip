@@ -174,6 +174,14 @@ __global__ void scale_channels_kernel(float *__restrict__ x, const float *__rest
     *reinterpret_cast<f32x4 *>(x + idx * 4) = v * sc;
 }
 
+__global__ void add_kernel(float *__restrict__ x, const float *__restrict__ y, long long n4) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = *reinterpret_cast<f32x4 *>(x + i * 4);
+    a += *reinterpret_cast<const f32x4 *>(y + i * 4);
+    *reinterpret_cast<f32x4 *>(x + i * 4) = a;
+}
+
 __global__ void fill_kernel(float *x, float v, long long n) {
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i < n) x[i] = v;
@@ -263,6 +271,14 @@ extern "C" int ml_scale_channels_f32(float *x, const float *s, int32_t B, int32_
     hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, x, s, HW, C / 4,
                        total);
     ML_CHECK_LAUNCH("scale_channels");
+    return ML_OK;
+}
+
+extern "C" int ml_add_f32(float *x, const float *y, int64_t n, void *stream) {
+    ML_REQUIRE(x && y && n > 0 && n % 4 == 0, "add: bad arguments (n %% 4)");
+    ML_REQUIRE(ml_aligned16(x) && ml_aligned16(y), "add: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)stream, x, y, (long long)(n / 4));
+    ML_CHECK_LAUNCH("add");
     return ML_OK;
 }
 

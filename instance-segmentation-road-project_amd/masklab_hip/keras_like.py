@@ -420,7 +420,10 @@ class Conv2DTranspose(Layer):
 
 
 class Dense(Layer):
-    """Dense without bias on a [B,1,1,C] map (SqueezeExcite, misc.py:34-40) = 1x1 conv."""
+    """Dense without bias on a [B,1,1,C] map (SqueezeExcite, misc.py:34-40) = 1x1 conv.
+    The MFMA conv reads 16-byte channel quads, so a width that is not a multiple of 4
+    (e.g. 160 // 16 = 10 in the decoder's SqueezeExcite) is carried in a zero-padded buffer:
+    the output tensor has ceil4(units) channels (extra ones 0) and the next Dense pads its kernel."""
 
     def __init__(self, units, activation=None, kernel_initializer="glorot_uniform", **kwargs):
         super().__init__(**kwargs)
@@ -436,8 +439,16 @@ class Dense(Layer):
         return tuple(input_shape[:-1]) + (self.units,)
 
     def _load_own(self, weights, device):
-        k = self._get(weights, "kernel").reshape(1, 1, self.cin, self.units)
-        self.dev = ops.DeviceConv(packing.pack_dense(k, None), device)
+        k = self._get(weights, "kernel")
+        cin_pad = -(-self.cin // 4) * 4
+        kp = np.zeros((1, 1, cin_pad, self.units), np.float32)
+        kp[0, 0, :self.cin] = k
+        self.dev = ops.DeviceConv(packing.pack_dense(kp, None), device)
 
     def call(self, x, **kwargs):
-        return ops.conv2d(x, self.dev, act=_lib.ACT_BY_NAME[self.activation])
+        import torch
+        units_pad = -(-self.units // 4) * 4
+        out = None
+        if units_pad != self.units:
+            out = torch.zeros(tuple(x.shape[:-1]) + (units_pad,), dtype=torch.float32, device=x.device)
+        return ops.conv2d(x, self.dev, act=_lib.ACT_BY_NAME[self.activation], out=out)

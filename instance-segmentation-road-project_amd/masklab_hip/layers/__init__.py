@@ -3,5 +3,5 @@ from .detection import *  # noqa: F401,F403
 from .detection import (BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, FeaturePyramid,
                         NormalizeBoxes, PriorLayer, RestoreBoxes)
 from .instance import MaskDistribute, MaskSubNet, PyramidRoiAlign
-from .misc import Identity, MoldBatch, ReLU, ResizeLike, SqueezeExcite
+from .misc import Identity, MobileSeparableConv2D, MoldBatch, ReLU, ResizeLike, SqueezeExcite
 from .semantic import ASPPNetwork, AtrousSeparableConv2D, SegmentationSubNet

@@ -9,7 +9,7 @@ from .. import ops
 from ..keras_like import Conv2D, Layer
 from ..normalization import GroupNormalization
 from ..prior import PriorBoxes
-from .misc import SqueezeExcite
+from .misc import MobileSeparableConv2D, SqueezeExcite
 
 
 class FeaturePyramid(Layer):
@@ -67,18 +67,22 @@ class _TowerMixin:
             if use_squeeze_excite:
                 block.append(SqueezeExcite(squeeze_ratio, name=f'{prefix}/se{i}'))
             if use_separable_conv:
-                raise NotImplementedError(
-                    "use_separable_conv=True (MobileSeparableConv2D, reference misc.py:57-117) is not built yet")
-            block.append(Conv2D(num_features, (3, 3), activation='relu', padding='same',
-                                kernel_initializer='normal', kernel_stddev=0.01, name=f'{prefix}/conv{i}'))
+                block.append(MobileSeparableConv2D(num_features, (3, 3), expand_ratio=expand_ratio,
+                                                   name=f'{prefix}/sep{i}'))
+            else:
+                block.append(Conv2D(num_features, (3, 3), activation='relu', padding='same',
+                                    kernel_initializer='normal', kernel_stddev=0.01, name=f'{prefix}/conv{i}'))
             block.append(GroupNormalization(groups, name=f'{prefix}/gn{i}'))
         return block
 
     @staticmethod
     def _run_tower(block, x):
+        block_input = x                          # never modified in place (it is a caller's tensor)
         for layer in block:
             if isinstance(layer, GroupNormalization):
                 x = layer(x, inplace=True)      # conv output is a fresh tensor: normalise in place
+            elif isinstance(layer, SqueezeExcite):
+                x = layer(x, keep_input=(x is block_input))
             else:
                 x = layer(x)
         return x

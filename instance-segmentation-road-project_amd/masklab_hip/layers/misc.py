@@ -3,7 +3,8 @@
 import torch
 
 from .. import ops
-from ..keras_like import Dense, Layer
+from ..keras_like import Conv2D, Dense, DepthwiseConv2D, Layer
+from ..normalization import GroupNormalization
 
 
 class Identity(Layer):
@@ -80,6 +81,67 @@ class SqueezeExcite(Layer):
     def get_config(self):
         config = super().get_config()
         config.update({"ratio": self.ratio})
+        return config
+
+
+class MobileSeparableConv2D(Layer):
+    """Separable Convolution Layer With Inverted Residual Block (reference misc.py:57-117):
+    1x1 expand (no bias) -> GN -> ReLU -> depthwise 3x3 'same' (no bias) -> GN -> ReLU ->
+    1x1 squeeze (no bias) -> GN -> inputs + x.  ReLUs are fused into the GroupNormalization apply pass."""
+
+    def __init__(self, filters, kernel_size=(3, 3), expand_ratio=4., stride=1, groups=16, **kwargs):
+        prefix = kwargs.get('name', 'SeparableConv2d')
+        super().__init__(**kwargs)
+        self.filters = filters
+        self.kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.expand_ratio = expand_ratio
+        self.stride = stride
+        self.groups = groups
+        self.expand_conv2d = Conv2D(int(self.expand_ratio * filters), (1, 1), use_bias=False,
+                                    name=prefix + '_expand_conv')
+        self.expand_norm = GroupNormalization(groups=self.groups, name=prefix + '_expand_GN')
+        self.depth_conv2d = DepthwiseConv2D(self.kernel_size, (stride, stride), padding='same', use_bias=False,
+                                            name=prefix + '_depthwise')
+        self.depth_norm = GroupNormalization(groups=self.groups, name=prefix + '_depthwise_GN')
+        self.squeeze_conv2d = Conv2D(filters, (1, 1), use_bias=False, name=prefix + '_squeeze_conv')
+        self.squeeze_norm = GroupNormalization(groups=self.groups, name=prefix + '_squeeze_GN')
+
+    def children(self):
+        return [self.expand_conv2d, self.expand_norm, self.depth_conv2d, self.depth_norm,
+                self.squeeze_conv2d, self.squeeze_norm]
+
+    def weight_specs(self):
+        out = {}
+        for ch in self.children():
+            out.update(ch.weight_specs())
+        return out
+
+    def build(self, input_shape):
+        if int(input_shape[-1]) != self.filters or self.stride != 1:
+            # the reference's Add() needs identical shapes (misc.py:105)
+            raise ValueError(f"MobileSeparableConv2D: skip connection needs input channels == filters "
+                             f"({input_shape[-1]} vs {self.filters}) and stride 1")
+        s = self.expand_conv2d.build(input_shape)
+        s = self.expand_norm.build(s)
+        s = self.depth_conv2d.build(s)
+        s = self.depth_norm.build(s)
+        s = self.squeeze_conv2d.build(s)
+        self.built = True
+        return self.squeeze_norm.build(s)
+
+    def call(self, inputs, **kwargs):
+        x = self.expand_conv2d(inputs)
+        x = self.expand_norm(x, fuse_relu=True, inplace=True)
+        x = self.depth_conv2d(x)
+        x = self.depth_norm(x, fuse_relu=True, inplace=True)
+        x = self.squeeze_conv2d(x)
+        x = self.squeeze_norm(x, inplace=True)
+        return ops.add_(x, inputs)              # skip_connection (misc.py:105)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"filters": self.filters, "kernel_size": self.kernel_size, "expand_ratio": self.expand_ratio,
+                       "stride": self.stride, "groups": self.groups})
         return config
 
 

@@ -352,6 +352,17 @@ def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, r
     return out
 
 
+def add_(x, y):
+    """x += y (same shape)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    _require_dev(y, "y")
+    if x.shape != y.shape:
+        raise ValueError("add_: shape mismatch")
+    _lib.check(lib.ml_add_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "ml_add_f32")
+    return x
+
+
 def fill_(x, v):
     lib = _lib.load()
     _lib.check(lib.ml_fill_f32(_ptr(x), float(v), x.numel(), _stream()), "ml_fill_f32")

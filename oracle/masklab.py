@@ -240,16 +240,33 @@ def squeeze_excite(x, w, name):
     return x * se[:, None, None, :]
 
 
-def _tower(x, w, prefix, depth, groups, use_se):
+def mobile_separable_conv2d(x, w, name, groups=16, stride=1):
+    """MobileSeparableConv2D.call, misc.py:94-106: 1x1 expand (no bias) -> GN -> ReLU -> depthwise 3x3
+    'same' (no bias) -> GN -> ReLU -> 1x1 squeeze (no bias) -> GN -> inputs + x."""
+    y = T.conv2d(x, w[name + "_expand_conv/kernel"])
+    y = T.relu(_gn(y, w, name + "_expand_GN", groups))
+    y = T.depthwise_conv2d(y, w[name + "_depthwise/depthwise_kernel"], stride=stride, padding="same")
+    y = T.relu(_gn(y, w, name + "_depthwise_GN", groups))
+    y = T.conv2d(y, w[name + "_squeeze_conv/kernel"])
+    y = _gn(y, w, name + "_squeeze_GN", groups)
+    return x + y
+
+
+def _tower(x, w, prefix, depth, groups, use_se, use_sep=False):
+    """depth x [SqueezeExcite? ; Conv3x3+ReLU | MobileSeparableConv2D ; GN]
+    (detection.py:111-125,181-195; instance.py:179-193; semantic.py:205-217)."""
     for i in range(depth):
         if use_se:
             x = squeeze_excite(x, w, f"{prefix}/se{i}")
-        x = T.relu(T.conv2d(x, w[f"{prefix}/conv{i}/kernel"], w[f"{prefix}/conv{i}/bias"]))
+        if use_sep:
+            x = mobile_separable_conv2d(x, w, f"{prefix}/sep{i}")
+        else:
+            x = T.relu(T.conv2d(x, w[f"{prefix}/conv{i}/kernel"], w[f"{prefix}/conv{i}/bias"]))
         x = T.group_norm(x, w[f"{prefix}/gn{i}/gamma"], w[f"{prefix}/gn{i}/beta"], groups)
     return x
 
 
-def classification_subnet(features, w, num_classes, depth, groups, use_se=False,
+def classification_subnet(features, w, num_classes, depth, groups, use_se=False, use_sep=False,
                           prefix="classification_sub_net"):
     """ClassificationSubNet.call, detection.py:204-212 (ctor :162-202): per level own
     block: depth x [conv3x3+ReLU (:190) ; GN (:194)] ; conv3x3 -> priors*classes + sigmoid
@@ -257,19 +274,19 @@ def classification_subnet(features, w, num_classes, depth, groups, use_se=False,
     heads = []
     for l, x in enumerate(features):
         p = f"{prefix}/block{l}"
-        x = _tower(x, w, p, depth, groups, use_se)
+        x = _tower(x, w, p, depth, groups, use_se, use_sep)
         x = T.sigmoid(T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"]))
         heads.append(x.reshape(x.shape[0], -1, num_classes))
     return np.concatenate(heads, axis=1)
 
 
-def box_regression_subnet(features, w, depth, groups, use_se=False,
+def box_regression_subnet(features, w, depth, groups, use_se=False, use_sep=False,
                           prefix="box_regression_sub_net"):
     """BoxRegressionSubNet.call, detection.py:132-140 (ctor :93-130)."""
     heads = []
     for l, x in enumerate(features):
         p = f"{prefix}/block{l}"
-        x = _tower(x, w, p, depth, groups, use_se)
+        x = _tower(x, w, p, depth, groups, use_se, use_sep)
         x = T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"])
         heads.append(x.reshape(x.shape[0], -1, 4))
     return np.concatenate(heads, axis=1)
@@ -366,14 +383,14 @@ def pyramid_roi_align(fmaps, dist_boxes, image_hw, crop_size=(14, 14)):
     return roi_fmaps, roi_boxes
 
 
-def mask_subnet(roi_fmaps, w, depth, groups, use_se=False, prefix="mask_sub_net"):
+def mask_subnet(roi_fmaps, w, depth, groups, use_se=False, use_sep=False, prefix="mask_sub_net"):
     """MaskSubNet.call, instance.py:203-225 (ctor :162-201)."""
     heads = []
     for k, x in enumerate(roi_fmaps):
         B, n = x.shape[:2]
         p = f"{prefix}/block{k}"
         x = x.reshape((B * n,) + x.shape[2:])
-        x = _tower(x, w, p, depth, groups, use_se)
+        x = _tower(x, w, p, depth, groups, use_se, use_sep)
         x = T.relu(T.conv2d_transpose_2x2_s2(x, w[p + "/deconv/kernel"], w[p + "/deconv/bias"]))
         x = T.sigmoid(T.conv2d(x, w[p + "/output/kernel"], w[p + "/output/bias"]))
         heads.append(x.reshape((B, n) + x.shape[1:]))
@@ -403,13 +420,13 @@ def aspp_network(x, w, atrous_rate=(6, 12, 18), groups=16):
     return T.relu(_gn(y, w, "concat_projection_GN", groups))                            # :156-157
 
 
-def segmentation_subnet(aspp_out, skip, w, depth, groups, use_se=False,
+def segmentation_subnet(aspp_out, skip, w, depth, groups, use_se=False, use_sep=False,
                         prefix="segmentation_sub_net"):
     """SegmentationSubNet.call, semantic.py:221-231 (ctor :183-219)."""
     s = T.relu(_gn(T.conv2d(skip, w["skip_projection/kernel"]), w, "skip_projection_GN", groups))
     up = T.resize_bilinear_align_corners(aspp_out, s.shape[1], s.shape[2])              # :226
     x = np.concatenate([up, s], axis=-1)                                                # :227
-    x = _tower(x, w, prefix, depth, groups, use_se)
+    x = _tower(x, w, prefix, depth, groups, use_se, use_sep)
     return T.sigmoid(T.conv2d(x, w[prefix + "/output/kernel"], w[prefix + "/output/bias"]))
 
 
@@ -437,9 +454,10 @@ def inference_forward(config, weights, images, dtype=np.float32, literal_groups=
         fouts = feature_pyramid(fpn_in, w, fpn_strides) + rest                          # :443-444
         internals["features"] = fouts
         cls_pred = classification_subnet(fouts, w, num_classes, det.num_depth, det.groups,
-                                         det.use_squeeze_excite)
+                                         det.use_squeeze_excite, det.use_separable_conv)
         loc_pred = box_regression_subnet(fouts, w, det.num_depth, det.groups,
-                                         det.use_separable_conv)   # builder quirk :95
+                                         det.use_separable_conv,   # builder quirk :95 (SE flag)
+                                         det.use_separable_conv)
         outs += [cls_pred, loc_pred]
         if with_instance:
             ins = config.instance
@@ -453,7 +471,7 @@ def inference_forward(config, weights, images, dtype=np.float32, literal_groups=
                                                      tuple(ins.crop_size))              # :468-469
             roi_fmaps = [f.astype(dtype) for f in roi_fmaps]
             roi_masks = mask_subnet(roi_fmaps, w, ins.num_depth, ins.groups,
-                                    ins.use_squeeze_excite)                             # :470
+                                    ins.use_squeeze_excite, ins.use_separable_conv)     # :470
             outs += [roi_boxes, roi_masks]
             internals.update(boxes=boxes, proposed=proposed, kept=kept, dist=dist,
                              roi_fmaps=roi_fmaps)
@@ -462,7 +480,7 @@ def inference_forward(config, weights, images, dtype=np.float32, literal_groups=
         fmap = dict(zip(names, feats))
         aspp = aspp_network(fmap[sem.aspp_input_name], w, tuple(sem.atrous_rate), sem.atrous_groups)
         seg = segmentation_subnet(aspp, fmap[sem.skip_input_name], w, sem.num_depth, sem.groups,
-                                  sem.use_squeeze_excite)
+                                  sem.use_squeeze_excite, sem.use_separable_conv)
         internals["aspp"] = aspp
         outs.append(seg)
     return (outs, internals) if return_internals else outs

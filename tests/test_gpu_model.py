@@ -142,3 +142,28 @@ def test_batch_sharding_equals_full_batch():
     assert torch.equal(torch.cat([p["counts"] for p in parts]), full["counts"])
     assert torch.equal(torch.cat([p["proposed"] for p in parts]), full["proposed"])
     assert torch.equal(torch.cat(segs), seg_full)
+
+
+def test_full_forward_with_squeeze_excite_and_separable_conv():
+    """the optional tower variants (flags off by default; the reference's shipped
+    project config turns SqueezeExcite on).  Builder quirks kept: the box tower's SE flag is
+    `use_separable_conv`, mask/seg heads get expand_ratio = use_separable_conv (= 1)."""
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = "mobilenet"
+    cfg.detection.use_separable_conv = True
+    cfg.detection.use_squeeze_excite = True
+    cfg.instance.use_separable_conv = True
+    cfg.instance.use_squeeze_excite = True
+    cfg.semantic.use_squeeze_excite = True        # separable decoder cannot build: 160-ch input vs 128 filters
+    cfg.detection.min_confidence = 0.02
+    _, model = R.construct_masklab_networks(cfg)
+    w = model.init_weights(4)
+    model.load_weights(w, "cuda:0")
+    images = np.random.default_rng(77).integers(0, 256, (2, 128, 128, 3), dtype=np.uint8)
+    got = model.predict(images)
+    want = O.inference_forward(cfg, w, images)
+    _check(model, got, want)
+    cfg.semantic.use_separable_conv = True
+    with pytest.raises(ValueError):
+        R.construct_masklab_networks(cfg)
