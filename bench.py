@@ -41,6 +41,7 @@ WORKLOADS = {
     "mobilenet_fpn_aspp_b1_1024": ("mobilenet", 1, 1024, 1024, "full"),  # BASELINE configs[1] (heads on device too)
     "mobilenet_full_b1_512": ("mobilenet", 1, 512, 512, "full"),         # BASELINE configs[0] shape
     "resnext50_full_b2_256": ("resnext50", 2, 256, 256, "full"),         # quick functional check
+    "resnext101_full_b16_1280_f32": ("resnext101", 16, 1280, 1280, "full"),  # BASELINE configs[4] shape, fp32 path
 }
 
 

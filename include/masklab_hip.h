@@ -109,11 +109,13 @@ int ml_maxpool3x3s2_f32(const float *in, float *out, int32_t B, int32_t H, int32
                         int32_t Ho, int32_t Wo, int32_t pad_t, int32_t pad_l, void *stream);
 
 /* BackBonePreProcess (engine/backbone/base.py:57-75) fused with the NHWC->NHWC4 repack the
- * MFMA stem wants: out[...,k] = (in[..., flip?2-k:k] - mean[k]) * scale + shift, out[...,3]=0.
- * in is uint8 (is_u8=1) or float32 RGB [B,H,W,3]; out_c is 3 or 4.                          */
+ * MFMA stem wants: out[...,k] = (in[..., flip?2-k:k] - mean[k]) / div[k] + shift[k], out[...,3]=0
+ * (per-channel div covers normalize=3 :71-73 and the ResNeXt-101 `bn_data` input BatchNorm,
+ * thirdparty/classification_models/models/resnext.py:194, which precedes the zero padding).
+ * in is uint8 (is_u8=1) or float32 RGB [B,H,W,3]; out_c is 3 or 4; mean/div/shift: 3 host floats. */
 int ml_preprocess_f32(const void *in, int32_t is_u8, float *out, int64_t npix, int32_t out_c,
-                      int32_t flip, float mean0, float mean1, float mean2,
-                      float scale, float shift, void *stream);
+                      int32_t flip, const float *mean, const float *div, const float *shift,
+                      void *stream);
 
 /* ---------------------------------------------------------------- GroupNormalization
  * The reference's chunk-wise GroupNormalization (engine/normalization.py:116-160):

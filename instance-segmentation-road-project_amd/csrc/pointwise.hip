@@ -11,8 +11,10 @@ constexpr int TPB = 256;
 inline unsigned grid_for(long long n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 // ------------------------------------------------------------------ preprocess
+struct Affine3 { float m[3], d[3], s[3]; };
+
 __global__ void preprocess_kernel(const void *in, int is_u8, float *out, long long npix, int out_c,
-                                  int flip, float m0, float m1, float m2, float scale, float shift) {
+                                  int flip, Affine3 a) {
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= npix) return;
     float v[3];
@@ -24,11 +26,10 @@ __global__ void preprocess_kernel(const void *in, int is_u8, float *out, long lo
         v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
     }
     if (flip) { const float t = v[0]; v[0] = v[2]; v[2] = t; }
-    // reference order: (x - mean) / (1/scale) (+ shift); scale is passed as the divisor's reciprocal
-    // only when exact (127.5 is not a power of two) -> we divide to stay bit-close to x/127.5.
-    const float r0 = (v[0] - m0) / scale + shift;
-    const float r1 = (v[1] - m1) / scale + shift;
-    const float r2 = (v[2] - m2) / scale + shift;
+    // reference order: (x - mean) / divisor (+ shift); a true division keeps x/127.5 bit-close
+    const float r0 = (v[0] - a.m[0]) / a.d[0] + a.s[0];
+    const float r1 = (v[1] - a.m[1]) / a.d[1] + a.s[1];
+    const float r2 = (v[2] - a.m[2]) / a.d[2] + a.s[2];
     if (out_c == 4) {
         f32x4 o = {r0, r1, r2, 0.f};
         *reinterpret_cast<f32x4 *>(out + i * 4) = o;
@@ -190,14 +191,16 @@ __global__ void fill_kernel(float *x, float v, long long n) {
 }  // namespace
 
 extern "C" int ml_preprocess_f32(const void *in, int32_t is_u8, float *out, int64_t npix, int32_t out_c,
-                                 int32_t flip, float mean0, float mean1, float mean2, float scale,
-                                 float shift, void *stream) {
-    ML_REQUIRE(in && out && npix > 0, "preprocess: bad arguments");
+                                 int32_t flip, const float *mean, const float *div, const float *shift,
+                                 void *stream) {
+    ML_REQUIRE(in && out && npix > 0 && mean && div && shift, "preprocess: bad arguments");
     ML_REQUIRE(out_c == 3 || out_c == 4, "preprocess: out_c must be 3 or 4");
-    ML_REQUIRE(scale != 0.f, "preprocess: zero divisor");
+    ML_REQUIRE(div[0] != 0.f && div[1] != 0.f && div[2] != 0.f, "preprocess: zero divisor");
+    Affine3 a;
+    for (int k = 0; k < 3; ++k) { a.m[k] = mean[k]; a.d[k] = div[k]; a.s[k] = shift[k]; }
     if (out_c == 4) ML_REQUIRE(ml_aligned16(out), "preprocess: out must be 16-byte aligned");
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(npix)), dim3(TPB), 0, (hipStream_t)stream, in, is_u8, out,
-                       (long long)npix, out_c, flip, mean0, mean1, mean2, scale, shift);
+                       (long long)npix, out_c, flip, a);
     ML_CHECK_LAUNCH("preprocess");
     return ML_OK;
 }

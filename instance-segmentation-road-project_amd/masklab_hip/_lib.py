@@ -49,7 +49,8 @@ SIGNATURES = {
     "ml_gconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
-    "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), _vp]),
     "ml_groupnorm_workspace_bytes": (_i64, [_i32, _i32]),
     "ml_groupnorm_chunk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
     "ml_resize_bilinear_ac_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 12 + [_vp]),

@@ -2,3 +2,4 @@
 from .base import BACKBONE_LAYERS, BackBonePreProcess, BackboneModel, load_backbone
 from .mobilenet import MobileNetV1
 from .resnext import ResNeXt50
+from .resnext101 import ResNeXt101

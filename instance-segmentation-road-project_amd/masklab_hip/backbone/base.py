@@ -14,6 +14,9 @@ from ..normalization import GroupNormalization
 BACKBONE_LAYERS = {
     "resnext50": {"C1": 'conv1_relu', "C2": 'conv2_block3_out', "C3": "conv3_block4_out",
                   "C4": "conv4_block6_out", "C5": "conv5_block3_out"},
+    # build-side extension: architecture from the vendored thirdparty model zoo
+    "resnext101": {"C1": "relu0", "C2": "stage1_unit3_relu", "C3": "stage2_unit4_relu",
+                   "C4": "stage3_unit23_relu", "C5": "stage4_unit3_relu"},
     "mobilenet": {"C1": "conv_pw_1_relu", "C2": "conv_pw_3_relu", "C3": "conv_pw_5_relu",
                   "C4": "conv_pw_11_relu", "C5": "conv_pw_13_relu"},
 }
@@ -32,6 +35,7 @@ class BackBonePreProcess(Layer):
         super().__init__(**kwargs)
         self.mean = [123.68, 116.779, 103.939] if rgb else [103.939, 116.779, 123.68]
         self.std = [0.225, 0.224, 0.229] if rgb else [0.229, 0.224, 0.225]
+        self.extra_affine = None      # (mean, divisor, shift) of a model-owned input BatchNorm (ResNeXt-101 bn_data)
 
     def build(self, input_shape):
         self.built = True
@@ -44,10 +48,13 @@ class BackBonePreProcess(Layer):
         elif self.normalize == 2:
             div, shift = 127.5, (0.0 if self.mean_shift else -1.0)
         elif self.normalize == 3:
-            raise NotImplementedError("normalize=3 (per-channel std) is only used by backbones "
-                                      "outside the hot path (SE-ResNe(X)t, EfficientNet)")
+            div, shift = [255.0 * s for s in self.std], 0.0          # x / 255 / std (:71-73)
         else:
             div, shift = 1.0, 0.0
+        if self.extra_affine is not None:
+            if self.normalize != 0 or self.mean_shift:
+                raise NotImplementedError("an input BatchNorm is only combined with the raw (normalize=0) mode")
+            mean, div, shift = self.extra_affine
         return ops.preprocess(inputs, flip=not self.rgb, mean=mean, divisor=div, shift=shift,
                               out_channels=self.out_channels)
 
@@ -65,6 +72,7 @@ class BackboneModel(Layer):
         super().__init__(name=backbone_type, **kwargs)
         from .mobilenet import MobileNetV1
         from .resnext import ResNeXt50
+        from .resnext101 import ResNeXt101
         bt = backbone_type.lower()
         self.backbone_type = bt
         self.backbone_outputs = tuple(backbone_outputs)
@@ -72,6 +80,10 @@ class BackboneModel(Layer):
         if bt == 'resnext50':
             self.preprocess = BackBonePreProcess(rgb=True, mean_shift=True, normalize=2)      # :215-217
             self.body = ResNeXt50()
+            same = True
+        elif bt == 'resnext101':
+            self.preprocess = BackBonePreProcess(rgb=True, mean_shift=False, normalize=0)
+            self.body = ResNeXt101()
             same = True
         elif bt == 'mobilenet':
             self.preprocess = BackBonePreProcess(rgb=False, mean_shift=False, normalize=2)    # :254-256
@@ -120,6 +132,11 @@ class BackboneModel(Layer):
         for ch in self.children():
             out.update(ch.weight_specs())
         return out
+
+    def load_weights(self, weights, device):
+        super().load_weights(weights, device)
+        if hasattr(self.body, "input_affine"):
+            self.preprocess.extra_affine = self.body.input_affine(weights)
 
     def call(self, images, **kwargs):
         x = self.preprocess(images)

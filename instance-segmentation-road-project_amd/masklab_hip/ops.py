@@ -228,10 +228,13 @@ def preprocess(images, flip, mean, divisor, shift, out_channels=4):
     if ch != 3:
         raise ValueError("images must have 3 channels (RGB, 0..255)")
     out = torch.empty((B, H, W, out_channels), dtype=torch.float32, device=images.device)
+    f3 = C.c_float * 3
+    div3 = [float(divisor)] * 3 if np.isscalar(divisor) else [float(v) for v in divisor]
+    sh3 = [float(shift)] * 3 if np.isscalar(shift) else [float(v) for v in shift]
     with _Prof("preprocess", 0, images.numel() * images.element_size() + 4 * out.numel()):
         _lib.check(lib.ml_preprocess_f32(_ptr(images), int(images.dtype == torch.uint8), _ptr(out), B * H * W,
-                                         out_channels, int(flip), float(mean[0]), float(mean[1]), float(mean[2]),
-                                         float(divisor), float(shift), _stream()), "ml_preprocess_f32")
+                                         out_channels, int(flip), f3(*[float(m) for m in mean]), f3(*div3), f3(*sh3),
+                                         _stream()), "ml_preprocess_f32")
     return out
 
 

@@ -159,6 +159,42 @@ def resnext50(x, w, literal_groups=True):
     return taps
 
 
+def group_conv2d_sliced(x, k, stride):
+    """thirdparty GroupConv2D (_common_blocks.py:13-76): per group slice -> Conv2D('valid') -> concat.
+    k: [groups,3,3,c,c]; the ZeroPadding2D(1) that precedes it (resnext.py:84,122) is applied here."""
+    groups, c = k.shape[0], k.shape[3]
+    outs = []
+    for g in range(groups):
+        outs.append(T.conv2d(x[..., g * c:(g + 1) * c], k[g], None, stride=stride, padding=((1, 1), (1, 1))))
+    return np.concatenate(outs, axis=-1)
+
+
+def resnext101(x, w, repetitions=(3, 4, 23, 3)):
+    """thirdparty/classification_models/models/resnext.py:138-241 (ResNeXt101 :266-275), BN eps 2e-5 (:49).
+    Build-side extension: the reference never calls it."""
+    eps = 2e-5
+    taps = {}
+    x = T.batch_norm(x, None, w["bn_data/beta"], w["bn_data/moving_mean"], w["bn_data/moving_variance"], eps)  # :194
+    x = T.conv2d(x, w["conv0/kernel"], None, stride=2, padding=((3, 3), (3, 3)))                               # :195-196
+    x = T.relu(_bn(x, w, "bn0", eps))
+    taps["C1"] = x
+    x = T.max_pool(np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)                                          # :199-200
+    for stage, rep in enumerate(repetitions):
+        for block in range(rep):
+            base = f"stage{stage + 1}_unit{block + 1}_"
+            stride = 1 if (stage == 0 or block > 0) else 2                                                    # :209-216
+            y = T.relu(_bn(T.conv2d(x, w[base + "conv1/kernel"], None, padding="valid"), w, base + "bn1", eps))
+            y = T.relu(_bn(group_conv2d_sliced(y, w[base + "conv2/kernel"], stride), w, base + "bn2", eps))
+            y = _bn(T.conv2d(y, w[base + "conv3/kernel"], None, padding="valid"), w, base + "bn3", eps)
+            if block == 0:                                                                                     # conv_block :93-95
+                sc = _bn(T.conv2d(x, w[base + "sc/kernel"], None, stride=stride, padding="valid"), w, base + "sc_bn", eps)
+            else:
+                sc = x
+            x = T.relu(y + sc)
+        taps[f"C{stage + 2}"] = x
+    return taps
+
+
 MOBILENET_BLOCKS = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2)] + \
     [(512, 1)] * 5 + [(1024, 2), (1024, 1)]
 
@@ -188,6 +224,7 @@ def mobilenet_v1(x, w):
 PREPROCESS = {  # base.py:190-279
     "resnext50": dict(rgb=True, mean_shift=True, normalize=2),
     "mobilenet": dict(rgb=False, mean_shift=False, normalize=2),
+    "resnext101": dict(rgb=True, mean_shift=False, normalize=0),     # extension: raw RGB into bn_data
 }
 
 
@@ -198,7 +235,12 @@ def backbone_forward(images, w, backbone_type, backbone_outputs, literal_groups=
     if bt not in PREPROCESS:
         raise NotImplementedError(bt)
     x = backbone_preprocess(images, **PREPROCESS[bt])
-    taps = resnext50(x, w, literal_groups) if bt == "resnext50" else mobilenet_v1(x, w)
+    if bt == "resnext50":
+        taps = resnext50(x, w, literal_groups)
+    elif bt == "resnext101":
+        taps = resnext101(x, w)
+    else:
+        taps = mobilenet_v1(x, w)
     names, feats = [], []
     for key in ("C1", "C2", "C3", "C4", "C5"):                                        # :287-290
         if key in backbone_outputs:

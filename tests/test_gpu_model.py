@@ -48,7 +48,7 @@ def _check(model, got, want):
         assert err <= TOL, (name, err)
 
 
-@pytest.mark.parametrize("bt", ["mobilenet", "resnext50"])
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50", "resnext101"])
 def test_full_forward_matches_oracle(bt):
     cfg, model, w = _build(bt)
     images = np.random.default_rng(1234).integers(0, 256, (2, 128, 128, 3), dtype=np.uint8)

@@ -244,6 +244,16 @@ def test_preprocess(bt, dtype):
     np.testing.assert_allclose(got[..., :3], ref, atol=1e-6)
 
 
+def test_preprocess_standardisation_mode():
+    """normalize=3 (reference base.py:71-73; note the reference's RGB std order [0.225,0.224,0.229])"""
+    from masklab_hip.backbone import BackBonePreProcess
+    img = RNG.integers(0, 256, (1, 5, 6, 3)).astype(np.float32)
+    for rgb in (True, False):
+        ref = O.backbone_preprocess(img, rgb=rgb, mean_shift=True, normalize=3)
+        got = host(BackBonePreProcess(rgb=rgb, mean_shift=True, normalize=3)(dev(img)))[..., :3]
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)
+
+
 # ------------------------------------------------------------------ GroupNormalization (chunk-norm)
 @pytest.mark.parametrize("shape,G,relu", [((2, 16, 16, 128), 16, False), ((3, 14, 14, 128), 16, False),
                                           ((2, 32, 32, 32), 16, True), ((2, 2, 2, 128), 32, False),
