@@ -26,11 +26,29 @@
 //   slab and a second kernel reduces them in a FIXED order (deterministic, no atomics).
 //   Block -> tile map is XCD aware: the NB column tiles that share one 128-pixel A panel get
 //   ids congruent mod 8, i.e. the same XCD / L2.
+#include <stdlib.h>
 #include "common.h"
+
+#ifdef MASKLAB_STAMPS
+__device__ unsigned long long g_stamps[8 * 64];
+#define STAMP(slot) do { if (stamp_on && it < 64) g_stamps[(slot) * 64 + it] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP1(idx) do { if ((blockIdx.x == 16) && (threadIdx.x == 0)) g_stamps[7 * 64 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ml_debug_read_stamps(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP1(idx) do {} while (0)
+#endif
 
 namespace {
 
 constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
+
+// Out-of-image taps read this zero line instead of being zeroed AFTER the load: any post-load select
+// forces the compiler to wait for the load (s_waitcnt vmcnt) BEFORE the MFMA block, which exposed a
+// full global-load latency in every K iteration.
+__device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
 constexpr int MAXP = ML_CONV_MAX_PROBLEMS;
 
 struct Problem {
@@ -107,6 +125,7 @@ conv_mfma_kernel(const MultiArgs args) {
     constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
     static_assert(BM * C_LD <= 2 * BUF, "epilogue tile must fit in the staging buffers");
     extern __shared__ __align__(16) float lds[];
+    STAMP1(0);
 
     // ---- which problem / tile / K slice
     int pi = 0;
@@ -134,9 +153,13 @@ conv_mfma_kernel(const MultiArgs args) {
     const int ld_row = tid >> 3;
     const int ld_c = (tid & 7) * 4;
 
-    // ---- per-thread pixel coordinates of the A rows it stages
-    int a_iy0[A_LD], a_ix0[A_LD], a_pix[A_LD];
+    // ---- per-thread pixel coordinates of the A rows it stages.  a_off0[i] = element offset of the
+    // row's tap-(0,0) pixel, channel gofs + ld_c: per chunk only a wave-uniform (tap, channel) offset
+    // is added, so the K loop's address arithmetic is one 64-bit add + two compares per row.
+    int a_iy0[A_LD], a_ix0[A_LD];
+    long long a_off0[A_LD];
     const int HoWo = p.Ho * p.Wo;
+    const int gofs = p.in_coff + nt * p.group_cin_step;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + ld_row + 32 * i;
@@ -147,20 +170,21 @@ conv_mfma_kernel(const MultiArgs args) {
             const int ox = r - oy * p.Wo;
             a_iy0[i] = oy * p.stride - p.pad_t;
             a_ix0[i] = ox * p.stride - p.pad_l;
-            a_pix[i] = b * p.H * p.W;
+            a_off0[i] = ((long long)b * p.H * p.W + (long long)a_iy0[i] * p.W + a_ix0[i]) * (long long)p.in_cstride +
+                        gofs + ld_c;
         } else {
             a_iy0[i] = -(1 << 28);
             a_ix0[i] = 0;
-            a_pix[i] = 0;
+            a_off0[i] = 0;
         }
     }
-    const int gofs = p.in_coff + nt * p.group_cin_step;
     const float *wrow = p.wgt + (size_t)(n0 + ld_row) * ktot + ld_c;
     // hot descriptor fields in registers: the descriptor lives in kernarg memory and would be
     // re-fetched (s_load + lgkmcnt(0), which also drains LDS) inside the K loop otherwise
     const int pH = p.H, pW = p.W, pKW = p.KW, pdil = p.dil, pspan = p.span, pshift = p.cpp_shift;
     const long long pcs = p.in_cstride;
     const float *pin = p.in;
+    const bool simple_span = (pshift == 30) && (pspan % 32 == 0);   // no pixel-spanning taps, no channel tail
 
     // chunk range of this K slice
     const int total_chunks = p.KH * p.KW * ncpt;
@@ -183,7 +207,7 @@ conv_mfma_kernel(const MultiArgs args) {
     const bool direct = (P.splits == 1);
     const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
     f32x4 res[E_ROWS];
-    const bool pre_res = direct && p.residual && vec_ok;
+    const bool pre_res = direct && p.residual && vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID;
     if (pre_res) {
 #pragma unroll
         for (int i = 0; i < E_ROWS; ++i) {
@@ -196,20 +220,23 @@ conv_mfma_kernel(const MultiArgs args) {
 
     f32x4 areg[A_LD], breg[B_LD];
     auto load_chunk = [&](int kc) {
-        const int c = cc * 32 + ld_c;
-        const int px = c >> pshift;
         const int dy = kh * pdil, dx = kw * pdil;
+        const long long toff = ((long long)dy * pW + dx) * pcs + cc * 32;   // wave-uniform
+        int px = 0;
+        bool c_ok = true;
+        if (!simple_span) {
+            const int c = cc * 32 + ld_c;
+            px = c >> pshift;
+            c_ok = c < pspan;
+        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int iy = a_iy0[i] + dy;
             const int ix = a_ix0[i] + dx;
-            const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + px) < (unsigned)pW) && (c < pspan);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const long long off = (long long)(a_pix[i] + iy * pW + ix) * pcs + gofs + c;
-                v = *reinterpret_cast<const f32x4 *>(pin + off);
-            }
-            areg[i] = v;
+            const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + px) < (unsigned)pW) && c_ok;
+            // branch-free and post-processing-free: the pointer (not the value) is selected
+            const float *src = ok ? pin + (a_off0[i] + toff) : g_zero_line;
+            areg[i] = *reinterpret_cast<const f32x4 *>(src);
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
@@ -243,15 +270,25 @@ conv_mfma_kernel(const MultiArgs args) {
     const int a_off = (wm * TM * 32 + r) * LDS_LD + h * 4;
     const int b_off = BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
 
+    STAMP1(1);
     if (kc_begin < kc_end) {
         load_chunk(kc_begin);
         store_chunk(0);
     }
     __syncthreads();
+    STAMP1(2);
 
+#ifdef MASKLAB_STAMPS
+    const bool stamp_on = (blockIdx.x == 16) && (threadIdx.x == 0);
+#endif
     for (int kc = kc_begin; kc < kc_end; ++kc) {
+#ifdef MASKLAB_STAMPS
+        const int it = kc - kc_begin;
+#endif
+        STAMP(0);
         const int buf = (kc - kc_begin) & 1;
         if (kc + 1 < kc_end) load_chunk(kc + 1);
+        STAMP(1);
         const float *base = lds + buf * BUF;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -270,10 +307,14 @@ conv_mfma_kernel(const MultiArgs args) {
                     for (int ni = 0; ni < TN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
         }
+        STAMP(2);
         if (kc + 1 < kc_end) store_chunk(buf ^ 1);
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
     }
 
+    STAMP1(3);
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Transpose the BM x BN tile through LDS (all staging reads finished at the barrier above).
 #pragma unroll
@@ -300,15 +341,56 @@ conv_mfma_kernel(const MultiArgs args) {
         return;
     }
     if (n >= p.cout) return;
+    if (vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID) {
+        // fast path (every backbone / tower conv): dense or channel-sliced NHWC destination, float4 lanes,
+        // ReLU / ReLU6 / none as a branch-free clamp.  Row pointers advance by a constant stride.
+        const float lo = (p.act == ML_ACT_NONE) ? -3.402823466e38f : 0.f;
+        const float hi = (p.act == ML_ACT_RELU6) ? 6.f : 3.402823466e38f;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+        const bool late_res = p.residual && !pre_res;
+        const size_t cs = p.out_cstride;
+        size_t off;
+        if (p.out_bstride) {
+            // per-image strided destination: rows of one tile may straddle images, keep the division
+            off = 0;
+        } else {
+            off = (size_t)(m0 + r0) * cs + p.out_coff + n;
+        }
 #pragma unroll
-    for (int i = 0; i < E_ROWS; ++i) {
-        const int rr = r0 + i * ROWS_PER_PASS;
-        const int m = m0 + rr;
-        if (m >= M) break;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4);
-        if (pre_res) v += res[i];
-        store_out4(p, HoWo, m, n, v, vec_ok, !pre_res);
+        for (int i = 0; i < E_ROWS; ++i) {
+            const int rr = r0 + i * ROWS_PER_PASS;
+            const int m = m0 + rr;
+            if (m >= M) break;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4) + bv;
+            if (pre_res) v += res[i];
+            if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
+            size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
+            if (p.out_bstride) {
+                const int b = m / HoWo;
+                o = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * cs + p.out_coff + n;
+            }
+            *reinterpret_cast<f32x4 *>(p.out + o) = v;
+        }
+    } else {
+        // generic path (sigmoid heads, Conv2DTranspose pixel shuffle, non-multiple-of-4 channel counts):
+        // deliberately NOT unrolled -- it is the rare case and used to bloat the epilogue to 13.8 k instructions
+#pragma unroll 1
+        for (int i = 0; i < E_ROWS; ++i) {
+            const int rr = r0 + i * ROWS_PER_PASS;
+            const int m = m0 + rr;
+            if (m >= M) break;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4);
+            store_out4(p, HoWo, m, n, v, vec_ok, true);
+        }
     }
+    STAMP1(4);
+#ifdef MASKLAB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP1(5);
+#endif
 }
 
 // out = act(sum_s slab[s] + bias + residual), slices summed in index order (deterministic)
@@ -386,7 +468,10 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
-    constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
+    constexpr int LDS_BYTES0 = 2 * (BM + BN) * LDS_LD * 4;
+    static int lds_pad = -1;
+    if (lds_pad < 0) { const char *e = getenv("MASKLAB_CONV_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }   // experiment knob
+    const int LDS_BYTES = LDS_BYTES0 + lds_pad;
     auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN>;
     static bool attr_set = false;
     if (!attr_set) {
