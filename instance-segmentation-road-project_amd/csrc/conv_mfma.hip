@@ -51,8 +51,28 @@ constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
 __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
 constexpr int MAXP = ML_CONV_MAX_PROBLEMS;
 
+// Exact unsigned division by a launch-invariant divisor for 0 <= n < 2^31 (Granlund-Montgomery):
+// s = ceil(log2 d), mul = ceil(2^(31+s) / d) (< 2^32), n / d = umulhi(n, mul) >> (s - 1).  d == 1: shift < 0.
+struct FastDiv { unsigned mul; int shift; };
+
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    if (d <= 1) { f.mul = 0; f.shift = -1; return f; }
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    const unsigned long long num = 1ull << (31 + s);
+    f.mul = (unsigned)((num + d - 1) / d);
+    f.shift = s - 1;
+    return f;
+}
+
+__device__ __forceinline__ int fast_div(int n, const FastDiv f) {
+    return f.shift < 0 ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shift);
+}
+
 struct Problem {
     ml_conv2d_desc d;
+    FastDiv div_howo, div_wo;
     int MB, NB, M, ncpt, ktot;
     int splits, cps;          // K slices and chunks per slice (splits == 1: direct epilogue)
     int blocks_per_split;     // 8*ceil(MB/8)*NB
@@ -145,6 +165,7 @@ conv_mfma_kernel(const MultiArgs args) {
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
+    STAMP1(8);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -160,13 +181,14 @@ conv_mfma_kernel(const MultiArgs args) {
     long long a_off0[A_LD];
     const int HoWo = p.Ho * p.Wo;
     const int gofs = p.in_coff + nt * p.group_cin_step;
+    STAMP1(9);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + ld_row + 32 * i;
         if (m < M) {
-            const int b = m / HoWo;
+            const int b = fast_div(m, P.div_howo);
             const int r = m - b * HoWo;
-            const int oy = r / p.Wo;
+            const int oy = fast_div(r, P.div_wo);
             const int ox = r - oy * p.Wo;
             a_iy0[i] = oy * p.stride - p.pad_t;
             a_ix0[i] = ox * p.stride - p.pad_l;
@@ -206,6 +228,7 @@ conv_mfma_kernel(const MultiArgs args) {
     const int n = n0 + c4;
     const bool direct = (P.splits == 1);
     const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
+    STAMP1(10);
     f32x4 res[E_ROWS];
     const bool pre_res = direct && p.residual && vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID;
     if (pre_res) {
@@ -219,9 +242,15 @@ conv_mfma_kernel(const MultiArgs args) {
     }
 
     f32x4 areg[A_LD], breg[B_LD];
+    // running wave-uniform state of the NEXT chunk: tap offsets (dy, dx), element offset toff of
+    // (tap, channel chunk) relative to a row's tap-(0,0) pixel -- updated with scalar adds only
+    int dy = kh * pdil, dx = kw * pdil;
+    int toff = (int)(((long long)dy * pW + dx) * pcs) + cc * 32;
+    const int step_kw = (int)(pdil * pcs) - (ncpt - 1) * 32;                       // next tap in the row
+    const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs) - (ncpt - 1) * 32;
+    const float *zero_ptr = g_zero_line;
+    asm volatile("" : "+v"(zero_ptr));     // opaque: keeps the address in VGPRs instead of s_getpc+s_load per use
     auto load_chunk = [&](int kc) {
-        const int dy = kh * pdil, dx = kw * pdil;
-        const long long toff = ((long long)dy * pW + dx) * pcs + cc * 32;   // wave-uniform
         int px = 0;
         bool c_ok = true;
         if (!simple_span) {
@@ -235,7 +264,8 @@ conv_mfma_kernel(const MultiArgs args) {
             const int ix = a_ix0[i] + dx;
             const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + px) < (unsigned)pW) && c_ok;
             // branch-free and post-processing-free: the pointer (not the value) is selected
-            const float *src = ok ? pin + (a_off0[i] + toff) : g_zero_line;
+            const float *src = pin + (a_off0[i] + toff);
+            src = ok ? src : zero_ptr;
             areg[i] = *reinterpret_cast<const f32x4 *>(src);
         }
 #pragma unroll
@@ -243,7 +273,10 @@ conv_mfma_kernel(const MultiArgs args) {
             breg[i] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * i) * ktot + (size_t)kc * 32);
         if (++cc == ncpt) {
             cc = 0;
-            if (++kw == pKW) { kw = 0; ++kh; }
+            if (++kw == pKW) { kw = 0; ++kh; dy += pdil; dx = 0; toff += step_kh; }
+            else { dx += pdil; toff += step_kw; }
+        } else {
+            toff += 32;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -327,7 +360,9 @@ conv_mfma_kernel(const MultiArgs args) {
                 const int col = wn * TN * 32 + ni * 32 + r;
                 lds[row * C_LD + col] = acc[mi][ni][e];
             }
+    STAMP1(11);
     __syncthreads();
+    STAMP1(12);
 
     if (!direct) {
         // raw partial tile -> slab[slice][m][n] (n_pad pitch); bias/act happen in the reduce kernel
@@ -357,22 +392,28 @@ conv_mfma_kernel(const MultiArgs args) {
         } else {
             off = (size_t)(m0 + r0) * cs + p.out_coff + n;
         }
+        // all LDS reads first (the accumulator registers are free now), then the stores: a serial
+        // read -> wait -> store chain cost 5300 cycles per tile
+        f32x4 tile_v[E_ROWS];
+#pragma unroll
+        for (int i = 0; i < E_ROWS; ++i)
+            tile_v[i] = *reinterpret_cast<const f32x4 *>(lds + (r0 + i * ROWS_PER_PASS) * C_LD + c4);
 #pragma unroll
         for (int i = 0; i < E_ROWS; ++i) {
-            const int rr = r0 + i * ROWS_PER_PASS;
-            const int m = m0 + rr;
-            if (m >= M) break;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + rr * C_LD + c4) + bv;
-            if (pre_res) v += res[i];
-            if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+            const int m = m0 + r0 + i * ROWS_PER_PASS;
+            if (m < M) {
+                f32x4 v = tile_v[i] + bv;
+                if (pre_res) v += res[i];
+                if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
-            size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
-            if (p.out_bstride) {
-                const int b = m / HoWo;
-                o = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * cs + p.out_coff + n;
+                for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
+                size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
+                if (p.out_bstride) {
+                    const int b = fast_div(m, P.div_howo);
+                    o = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * cs + p.out_coff + n;
+                }
+                *reinterpret_cast<f32x4 *>(p.out + o) = v;
             }
-            *reinterpret_cast<f32x4 *>(p.out + o) = v;
         }
     } else {
         // generic path (sigmoid heads, Conv2DTranspose pixel shuffle, non-multiple-of-4 channel counts):
@@ -496,6 +537,8 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.NB = d.n_pad / BN;
         P.ncpt = d.span_pad / 32;
         P.ktot = d.KH * d.KW * d.span_pad;
+        P.div_howo = make_fastdiv((unsigned)(d.Ho * d.Wo));
+        P.div_wo = make_fastdiv((unsigned)d.Wo);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
         int splits = (n == 1 && workspace) ? choose_splits((long long)P.MB * P.NB, chunks) : 1;

@@ -33,3 +33,6 @@ print("first 8 iterations:", [int(v) for v in tot[:8]])
 e = st[7, :6]
 print("kernel phases (cycles): entry->setup %d, first chunk load+store+barrier %d, K loop %d, epilogue issue %d, stores drained %d"
       % (e[1]-e[0], e[2]-e[1], e[3]-e[2], e[4]-e[3], e[5]-e[4]))
+f = st[7]
+print("setup detail: problem lookup %d, (to row setup) %d, row coords+offsets %d, rest of setup %d" % (f[8]-f[0], f[9]-f[8], f[10]-f[9], f[1]-f[10]))
+print("epilogue detail: acc->LDS %d, barrier %d, read+bias+act+store %d" % (f[11]-f[3], f[12]-f[11], f[4]-f[12]))
