@@ -45,10 +45,8 @@ namespace {
 
 constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
 
-// Out-of-image taps read this zero line instead of being zeroed AFTER the load: any post-load select
-// forces the compiler to wait for the load (s_waitcnt vmcnt) BEFORE the MFMA block, which exposed a
-// full global-load latency in every K iteration.
-__device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+// (out-of-image taps: the buffer loads below return zeros for out-of-range offsets -- no post-load select,
+// which would force an s_waitcnt vmcnt before the MFMA block)
 constexpr int MAXP = ML_CONV_MAX_PROBLEMS;
 
 // Exact unsigned division by a launch-invariant divisor for 0 <= n < 2^31 (Granlund-Montgomery):
@@ -73,6 +71,7 @@ __device__ __forceinline__ int fast_div(int n, const FastDiv f) {
 struct Problem {
     ml_conv2d_desc d;
     FastDiv div_howo, div_wo;
+    unsigned in_bytes, wgt_bytes;   // buffer-resource extents (num_records) of the activation / weight tensors
     int MB, NB, M, ncpt, ktot;
     int splits, cps;          // K slices and chunks per slice (splits == 1: direct epilogue)
     int blocks_per_split;     // 8*ceil(MB/8)*NB
@@ -174,11 +173,11 @@ conv_mfma_kernel(const MultiArgs args) {
     const int ld_row = tid >> 3;
     const int ld_c = (tid & 7) * 4;
 
-    // ---- per-thread pixel coordinates of the A rows it stages.  a_off0[i] = element offset of the
+    // ---- per-thread pixel coordinates of the A rows it stages.  a_voff[i] = byte offset of the
     // row's tap-(0,0) pixel, channel gofs + ld_c: per chunk only a wave-uniform (tap, channel) offset
     // is added, so the K loop's address arithmetic is one 64-bit add + two compares per row.
     int a_iy0[A_LD], a_ix0[A_LD];
-    long long a_off0[A_LD];
+    int a_voff[A_LD];          // byte offset (may be "negative" for halo rows; only used when the tap is valid)
     const int HoWo = p.Ho * p.Wo;
     const int gofs = p.in_coff + nt * p.group_cin_step;
     STAMP1(9);
@@ -192,21 +191,19 @@ conv_mfma_kernel(const MultiArgs args) {
             const int ox = r - oy * p.Wo;
             a_iy0[i] = oy * p.stride - p.pad_t;
             a_ix0[i] = ox * p.stride - p.pad_l;
-            a_off0[i] = ((long long)b * p.H * p.W + (long long)a_iy0[i] * p.W + a_ix0[i]) * (long long)p.in_cstride +
-                        gofs + ld_c;
+            a_voff[i] = (int)((((long long)b * p.H * p.W + (long long)a_iy0[i] * p.W + a_ix0[i]) * (long long)p.in_cstride +
+                               gofs + ld_c) * 4);
         } else {
             a_iy0[i] = -(1 << 28);
             a_ix0[i] = 0;
-            a_off0[i] = 0;
+            a_voff[i] = 0;
         }
     }
-    const float *wrow = p.wgt + (size_t)(n0 + ld_row) * ktot + ld_c;
     // hot descriptor fields in registers: the descriptor lives in kernarg memory and would be
     // re-fetched (s_load + lgkmcnt(0), which also drains LDS) inside the K loop otherwise
     const int pH = p.H, pW = p.W, pKW = p.KW, pdil = p.dil, pspan = p.span, pshift = p.cpp_shift;
     const long long pcs = p.in_cstride;
     const float *pin = p.in;
-    const bool simple_span = (pshift == 30) && (pspan % 32 == 0);   // no pixel-spanning taps, no channel tail
 
     // chunk range of this K slice
     const int total_chunks = p.KH * p.KW * ncpt;
@@ -248,36 +245,52 @@ conv_mfma_kernel(const MultiArgs args) {
     int toff = (int)(((long long)dy * pW + dx) * pcs) + cc * 32;
     const int step_kw = (int)(pdil * pcs) - (ncpt - 1) * 32;                       // next tap in the row
     const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs) - (ncpt - 1) * 32;
-    const float *zero_ptr = g_zero_line;
-    asm volatile("" : "+v"(zero_ptr));     // opaque: keeps the address in VGPRs instead of s_getpc+s_load per use
-    auto load_chunk = [&](int kc) {
-        int px = 0;
-        bool c_ok = true;
-        if (!simple_span) {
-            const int c = cc * 32 + ld_c;
-            px = c >> pshift;
-            c_ok = c < pspan;
-        }
+    // The next chunk's prefetch is split into PIECES (one A row or one B row each: ~12 VALU + 1 global
+    // load) that the K loop pins between individual MFMAs with sched_barrier(0): a wave that issues MFMAs
+    // back to back owns its SIMD's issue port, so non-MFMA work only overlaps matrix work when it sits in
+    // the 64-cycle shadow of the wave's OWN MFMAs.  All pieces are branch-free (selects / masks only).
+    int nx_px = 0;
+    bool nx_cok = true;
+    auto piece_begin = [&]() {
+        const int c = cc * 32 + ld_c;
+        nx_px = c >> pshift;                     // 0 unless a tap spans pixels (NHWC4 stems)
+        nx_cok = c < pspan;
+    };
+    // Buffer loads: address = resource base + per-lane byte offset (+ scalar offset); any offset >= num_records
+    // returns 0, so out-of-image taps need no zero line and no select on the DATA -- one v_cndmask on the offset.
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, (int)P.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, (int)P.wgt_bytes, 0x00020000);
+    int b_voff[B_LD];
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int iy = a_iy0[i] + dy;
-            const int ix = a_ix0[i] + dx;
-            const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + px) < (unsigned)pW) && c_ok;
-            // branch-free and post-processing-free: the pointer (not the value) is selected
-            const float *src = pin + (a_off0[i] + toff);
-            src = ok ? src : zero_ptr;
-            areg[i] = *reinterpret_cast<const f32x4 *>(src);
-        }
+    for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * 4;
+    auto piece_a = [&](int i) {
+        const int iy = a_iy0[i] + dy;
+        const int ix = a_ix0[i] + dx;
+        const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + nx_px) < (unsigned)pW) && nx_cok;
+        int vo = a_voff[i] + toff * 4;
+        vo = ok ? vo : (int)0x80000000;          // out of range => hardware returns zeros
+        areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
+    };
+    auto piece_b = [&](int i, int kc) {
+        breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], kc * 128, 0));
+    };
+    auto piece_end = [&]() {                     // advance (kh, kw, cc) and the running offsets with selects
+        const bool wrap_c = (cc + 1 == ncpt);
+        const bool wrap_w = wrap_c && (kw + 1 == pKW);
+        toff += wrap_w ? step_kh : (wrap_c ? step_kw : 32);
+        dx = wrap_w ? 0 : (wrap_c ? dx + pdil : dx);
+        dy = wrap_w ? dy + pdil : dy;
+        kw = wrap_w ? 0 : (wrap_c ? kw + 1 : kw);
+        kh = wrap_w ? kh + 1 : kh;
+        cc = wrap_c ? 0 : cc + 1;
+    };
+    auto load_chunk = [&](int kc) {              // un-interleaved form (prologue)
+        piece_begin();
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            breg[i] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * i) * ktot + (size_t)kc * 32);
-        if (++cc == ncpt) {
-            cc = 0;
-            if (++kw == pKW) { kw = 0; ++kh; dy += pdil; dx = 0; toff += step_kh; }
-            else { dx += pdil; toff += step_kw; }
-        } else {
-            toff += 32;
-        }
+        for (int i = 0; i < A_LD; ++i) piece_a(i);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) piece_b(i, kc);
+        piece_end();
     };
     auto store_chunk = [&](int buf) {
         float *As = lds + buf * BUF;
@@ -320,9 +333,17 @@ conv_mfma_kernel(const MultiArgs args) {
 #endif
         STAMP(0);
         const int buf = (kc - kc_begin) & 1;
-        if (kc + 1 < kc_end) load_chunk(kc + 1);
+        const bool more = kc + 1 < kc_end;
+        // Unconditional prefetch (the last iteration re-reads its own chunk and drops it): no branch.
+        const int kc_next = more ? kc + 1 : kc;
         STAMP(1);
         const float *base = lds + buf * BUF;
+        piece_begin();
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NPIECE = A_LD + B_LD + 1;              // + piece_end
+        constexpr int NMFMA = 16 * TM * TN;
+        constexpr int GAP = (NMFMA / 2) / NPIECE > 0 ? (NMFMA / 2) / NPIECE : 1;   // pieces ride in the first half
+        int placed = 0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f32x4 a[TM], b[TN];
@@ -337,11 +358,25 @@ conv_mfma_kernel(const MultiArgs args) {
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
+                    for (int ni = 0; ni < TN; ++ni) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+                        const int idx = ((ks * 4 + j) * TM + mi) * TN + ni;      // compile-time after unrolling
+                        if (idx % GAP == GAP - 1 && placed < NPIECE) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (placed < A_LD) piece_a(placed);
+                            else if (placed < A_LD + B_LD) piece_b(placed - A_LD, kc_next);
+                            else piece_end();
+                            ++placed;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
         }
         STAMP(2);
-        if (kc + 1 < kc_end) store_chunk(buf ^ 1);
+#ifdef MASKLAB_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(5);
+#endif
+        if (more) store_chunk(buf ^ 1);
         STAMP(3);
         __syncthreads();
         STAMP(4);
@@ -471,6 +506,9 @@ int validate(const ml_conv2d_desc &d) {
     ML_REQUIRE(d.cout > 0 && d.out_cstride > 0 && d.out_coff >= 0 && d.out_bstride >= 0, "conv2d: bad output channels");
     ML_REQUIRE((long long)d.B * d.H * d.W < (1ll << 31) / 2, "conv2d: too many input pixels for int32 indexing");
     ML_REQUIRE((long long)d.B * d.Ho * d.Wo < (1ll << 31) - 256, "conv2d: too many output pixels");
+    ML_REQUIRE((long long)d.B * d.H * d.W * d.in_cstride * 4 < (1ll << 31),
+               "conv2d: input tensor must be < 2 GiB (32-bit buffer offsets): shard the batch");
+    ML_REQUIRE((long long)d.n_pad * d.KH * d.KW * d.span_pad * 4 < (1ll << 31), "conv2d: weight tensor must be < 2 GiB");
     if (d.shuffle2x2) {
         ML_REQUIRE(d.cout % 4 == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Ho == d.H && d.Wo == d.W,
                    "conv2d: shuffle2x2 needs a 1x1 stride-1 problem with cout = 4*Cout");
@@ -539,6 +577,8 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.ktot = d.KH * d.KW * d.span_pad;
         P.div_howo = make_fastdiv((unsigned)(d.Ho * d.Wo));
         P.div_wo = make_fastdiv((unsigned)d.Wo);
+        P.in_bytes = (unsigned)((long long)d.B * d.H * d.W * d.in_cstride * 4);
+        P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * 4);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
         int splits = (n == 1 && workspace) ? choose_splits((long long)P.MB * P.NB, chunks) : 1;

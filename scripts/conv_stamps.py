@@ -28,6 +28,8 @@ d = [st[1, :n] - st[0, :n], st[2, :n] - st[1, :n], st[3, :n] - st[2, :n], st[4, 
 tot = st[0, 1:n] - st[0, :n - 1]
 for nm, v in zip(names, d):
     print(f"{nm:40s} median {np.median(v[1:n-1]):8.1f}  min {v[1:n-1].min():6d} max {v[1:n-1].max():6d}")
+w = st[5, :n] - st[2, :n]
+print(f"{'  of which: vmcnt(0) wait':40s} median {np.median(w[1:n-1]):8.1f}  min {w[1:n-1].min():6d} max {w[1:n-1].max():6d}")
 print(f"{'whole iteration':40s} median {np.median(tot):8.1f}")
 print("first 8 iterations:", [int(v) for v in tot[:8]])
 e = st[7, :6]
