@@ -196,9 +196,13 @@ conv_mfma_kernel(const MultiArgs args) {
         } else {
             a_iy0[i] = -(1 << 28);
             a_ix0[i] = 0;
-            a_voff[i] = 0;
+            a_voff[i] = (int)0x80000000;       // stays out of range after adding a (small, positive) tap offset
         }
     }
+    // 1x1 / stride-1 / unpadded convs (most of the backbone): every tap of a valid row is inside the image,
+    // so the per-row compares vanish and invalid tail rows rely on their out-of-range base offset.
+    const bool nohalo = (p.KH == 1) && (p.KW == 1) && (p.pad_t == 0) && (p.pad_l == 0) && (p.stride == 1) &&
+                        (p.cpp_shift == 30) && (p.span % 32 == 0);
     // hot descriptor fields in registers: the descriptor lives in kernarg memory and would be
     // re-fetched (s_load + lgkmcnt(0), which also drains LDS) inside the K loop otherwise
     const int pH = p.H, pW = p.W, pKW = p.KW, pdil = p.dil, pspan = p.span, pshift = p.cpp_shift;
@@ -264,11 +268,13 @@ conv_mfma_kernel(const MultiArgs args) {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * 4;
     auto piece_a = [&](int i) {
-        const int iy = a_iy0[i] + dy;
-        const int ix = a_ix0[i] + dx;
-        const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + nx_px) < (unsigned)pW) && nx_cok;
         int vo = a_voff[i] + toff * 4;
-        vo = ok ? vo : (int)0x80000000;          // out of range => hardware returns zeros
+        if (!nohalo) {                            // wave-uniform
+            const int iy = a_iy0[i] + dy;
+            const int ix = a_ix0[i] + dx;
+            const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + nx_px) < (unsigned)pW) && nx_cok;
+            vo = ok ? vo : (int)0x80000000;      // out of range => hardware returns zeros
+        }
         areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
     };
     auto piece_b = [&](int i, int kc) {
@@ -342,7 +348,7 @@ conv_mfma_kernel(const MultiArgs args) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NPIECE = A_LD + B_LD + 1;              // + piece_end
         constexpr int NMFMA = 16 * TM * TN;
-        constexpr int GAP = (NMFMA / 2) / NPIECE > 0 ? (NMFMA / 2) / NPIECE : 1;   // pieces ride in the first half
+        constexpr int GAP = NMFMA >= 4 * NPIECE ? 2 : 1;     // pieces ride early so the loads have the rest of the block to land
         int placed = 0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
