@@ -59,6 +59,28 @@ def build_model(backbone, device, seed=0, hot_cls=True):
     return cfg, model, w
 
 
+def measured_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/*_traffic.json,
+    produced by scripts/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH x2 gfx950 correction).  None when no such file travels with the repo."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2>", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1>",
+            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1>"}.get(kernel_label)
+    if want is None:
+        return None
+    try:
+        data = json.load(open(files[-1]))["kernels"]
+        for k, v in data.items():
+            if want in k:
+                return round(v["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(cfg, weights, H, W, max_seconds=60.0):
     """Oracle forward on the host (1 image).  Returns dict for the JSON line."""
     from oracle import masklab as O
@@ -156,16 +178,18 @@ def main():
                           "gbs": round(v["mbytes"] / max(v["ms"], 1e-9), 1)} for k, v in agg.items()}
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]
+        traffic = measured_traffic(dom)
         if dom.startswith("conv_mfma"):
             ach = d["gflop"] / d["ms"]          # GFLOP/ms = TFLOP/s
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": round(1e6 * d["mbytes"] / d["launches"]),
                         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                         "algorithmic_gflop_per_step": round(d["gflop"], 2)}
         else:
             ach = d["mbytes"] / d["ms"]         # MB/ms = GB/s
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
 
     cpu = None
