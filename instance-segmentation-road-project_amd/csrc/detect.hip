@@ -8,10 +8,11 @@
 // rounds exactly like the reference's separately-rounded TF ops.
 //
 // NMS formulation: TF's greedy loop (pop best score; keep unless IoU with an already kept box
-// > thr) is run as "select the best ALIVE candidate, then kill every alive candidate whose IoU
-// with it exceeds thr" -- identical result, and each of the <= max_out rounds is a flat parallel
-// sweep: a 64-bit key (score bits << 32 | ~index) makes the arg-max a plain max-reduction (wave
-// shuffles + one LDS hop) and breaks score ties towards the lower index.  No sort is needed.
+// > thr).  Candidates carry a 64-bit key (score bits << 32 | ~index): key order IS TF's pop order
+// (score descending, ties towards the lower index).  A band of candidates is sorted by key in LDS
+// (bitonic, whole block), then resolved 64 at a time by ONE wave with ballots and lane reads -- no
+// block barrier per selected box: the chunk is checked against the boxes already selected, then
+// the lowest alive lane is selected and kills its chunk-mates, until the chunk is empty.
 #include "common.h"
 #pragma clang fp contract(off)
 
@@ -58,6 +59,140 @@ __device__ __forceinline__ float iou_tf(const f32x4 a, const f32x4 b) {
     const float iy2 = fminf(ymax_i, ymax_j), ix2 = fminf(xmax_i, xmax_j);
     const float inter = fmaxf(iy2 - iy1, 0.f) * fmaxf(ix2 - ix1, 0.f);
     return inter / ((area_i + area_j) - inter);
+}
+
+// `iou_tf(a, b) > thr`, bit for bit, without paying for the IEEE division on every pair: the quotient
+// is first estimated with v_rcp_f32 (about 1 ulp); only when the estimate lies within 1e-5 (relative)
+// of the threshold -- or the union is so small that the reciprocal could overflow -- is the exact
+// division evaluated.  Outside that margin the correctly rounded quotient is on the same side of thr.
+__device__ __forceinline__ bool iou_gt(const f32x4 a, const f32x4 b, float thr) {
+    const float ymin_i = fminf(a[0], a[2]), xmin_i = fminf(a[1], a[3]);
+    const float ymax_i = fmaxf(a[0], a[2]), xmax_i = fmaxf(a[1], a[3]);
+    const float ymin_j = fminf(b[0], b[2]), xmin_j = fminf(b[1], b[3]);
+    const float ymax_j = fmaxf(b[0], b[2]), xmax_j = fmaxf(b[1], b[3]);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.f || area_j <= 0.f) return 0.f > thr;
+    const float iy1 = fmaxf(ymin_i, ymin_j), ix1 = fmaxf(xmin_i, xmin_j);
+    const float iy2 = fminf(ymax_i, ymax_j), ix2 = fminf(xmax_i, xmax_j);
+    const float inter = fmaxf(iy2 - iy1, 0.f) * fmaxf(ix2 - ix1, 0.f);
+    const float uni = (area_i + area_j) - inter;
+    if (uni > 1e-30f && uni < 1e30f) {
+        const float est = inter * __builtin_amdgcn_rcpf(uni);
+        if (est > thr * 1.00001f) return true;
+        if (est < thr * 0.99999f) return false;
+    }
+    return inter / uni > thr;
+}
+
+// Descending bitonic sort of P (power of two) keys in LDS by the whole block; `idx` (optional) is a
+// 16-bit payload permuted with the keys.  Keys are distinct except for the 0 padding.
+template <bool HAS_IDX>
+__device__ __forceinline__ void bitonic_sort_desc(u64 *key, unsigned short *idx, int P) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const bool desc = (i & k) == 0;
+                const u64 a = key[i], b = key[ixj];
+                if ((a < b) == desc) {
+                    key[i] = b;
+                    key[ixj] = a;
+                    if (HAS_IDX) {
+                        const unsigned short ia = idx[i];
+                        idx[i] = idx[ixj];
+                        idx[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+struct GreedyShared {
+    u64 supp[64];     // supp[i] bit j: candidate j of the chunk is suppressed by candidate i (j > i)
+    int dead[64];     // candidate suppressed by a box selected before this chunk
+    int picked;
+};
+
+// Greedy NMS over candidates SORTED by key (descending; 0 = dead/padding) in LDS.
+//   skey[m]  keys                                             sidx[m]  box slot of each key (HAS_IDX)
+//   bbox[]   corner boxes by slot (slot = sidx[j], or ~low32(key) when !HAS_IDX)
+//   sel[]    boxes selected so far (`picked` of them on entry, from earlier bands)
+// The list is consumed 64 candidates (one chunk) at a time:
+//   (1) whole block: wave w tests the chunk against the selected boxes q = w, w+nw, ... and against
+//       its share of the chunk's own 64x64 suppression matrix -- every IoU of the chunk in parallel;
+//   (2) wave 0: walks the alive mask with scalar bit operations only: select the lowest alive lane,
+//       clear the lanes it suppresses (its matrix row, fetched with a lane read), repeat.
+// So the serial part per selected box is ~10 instructions, and the IoU arithmetic is spread over
+// the block.  emit(picked, key, slot) runs on the selected candidate's lane only.
+// Called by all threads of the block (blockDim.x = 64 * nw, nw | 64); returns the new `picked`.
+template <bool HAS_IDX, class Emit>
+__device__ __forceinline__ int greedy_sorted(const u64 *skey, const unsigned short *sidx, const f32x4 *bbox, int m,
+                                             f32x4 *sel, int picked, int max_out, float thr, GreedyShared *gs,
+                                             Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const int bpw = 64 / nw;                             // matrix columns handled per wave
+    auto slot_of = [&](u64 k, int j) {
+        return HAS_IDX ? (int)sidx[j] : (int)(0xffffffffu - (unsigned)(k & 0xffffffffu));
+    };
+    if (tid < 64) { gs->supp[tid] = 0; gs->dead[tid] = 0; }
+    __syncthreads();
+    for (int base = 0; base < m && picked < max_out; base += 64) {
+        if (skey[base] == 0) break;                      // uniform: sorted, nothing alive from here on
+        const int j = base + lane;
+        const u64 k = j < m ? skey[j] : 0;
+        const int slot = k != 0 ? slot_of(k, j) : 0;
+        f32x4 box = {0.f, 0.f, 0.f, 0.f};
+        if (k != 0) box = bbox[slot];
+        // (1a) against the boxes selected before this chunk
+        if (k != 0) {
+            bool dead = false;
+            for (int q = wv; q < picked; q += nw)
+                if (iou_gt(box, sel[q], thr)) { dead = true; break; }
+            if (dead) gs->dead[lane] = 1;
+        }
+        // (1b) this wave's columns of the chunk's suppression matrix
+        {
+            u64 bits = 0;
+            for (int u = 0; u < bpw; ++u) {
+                const int jj = wv * bpw + u;
+                const int pj = base + jj;
+                const u64 kj = pj < m ? skey[pj] : 0;     // wave-uniform
+                if (kj == 0) break;                       // sorted: the rest of the chunk is padding
+                const f32x4 bj = bbox[slot_of(kj, pj)];
+                if (k != 0 && jj > lane && iou_gt(bj, box, thr)) bits |= 1ull << jj;
+            }
+            if (bits != 0) atomicOr(&gs->supp[lane], bits);
+        }
+        __syncthreads();
+        // (2) serial resolve on wave 0
+        if (tid < 64) {
+            const u64 row = gs->supp[lane];
+            const unsigned row_lo = (unsigned)row, row_hi = (unsigned)(row >> 32);
+            u64 mask = __ballot(k != 0 && gs->dead[lane] == 0);
+            while (mask != 0 && picked < max_out) {
+                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                if (lane == l) {
+                    sel[picked] = box;
+                    emit(picked, k, slot);
+                }
+                ++picked;
+                const u64 kill = ((u64)(unsigned)__builtin_amdgcn_readlane((int)row_hi, l) << 32) |
+                                 (u64)(unsigned)__builtin_amdgcn_readlane((int)row_lo, l);
+                mask &= ~(kill | (1ull << l));
+            }
+            gs->supp[lane] = 0;
+            gs->dead[lane] = 0;
+            if (lane == 0) gs->picked = picked;
+        }
+        __syncthreads();
+        picked = gs->picked;
+    }
+    return picked;
 }
 
 // NormalizeBoxes with the default shape (ones): pixel corners (detection.py:362,488)
@@ -128,25 +263,25 @@ __global__ void __launch_bounds__(256)
 det_threshold_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, int A, int C, float thr) {
     __shared__ int cnt[64], gbase[64], first[64];
     const int b = blockIdx.y;
-    const long long AC = (long long)A * C;
-    const long long e0 = (long long)blockIdx.x * DET_EPB;
+    const unsigned AC = (unsigned)A * (unsigned)C;            // < 2^31 (checked by the launcher)
+    const unsigned e0 = blockIdx.x * (unsigned)DET_EPB;
     if (threadIdx.x < C) { cnt[threadIdx.x] = 0; first[threadIdx.x] = 0x7fffffff; }
     __syncthreads();
     float sc[DET_EPT];
     int pos[DET_EPT];
 #pragma unroll
+    for (int k = 0; k < DET_EPT; ++k) {                       // all loads first, then the ranking
+        const unsigned e = e0 + k * 256 + threadIdx.x;        // (a*C + c) inside image b
+        sc[k] = e < AC ? cls[(long long)b * AC + e] : -INFINITY;
+    }
+#pragma unroll
     for (int k = 0; k < DET_EPT; ++k) {
-        const long long e = e0 + k * 256 + threadIdx.x;       // (a*C + c) inside image b
+        const unsigned e = e0 + k * 256 + threadIdx.x;
         pos[k] = -1;
-        sc[k] = 0.f;
-        if (e < AC) {
-            const float s = cls[(long long)b * AC + e];
-            if (s >= thr) {
-                const int c = (int)(e % C);
-                sc[k] = s;
-                pos[k] = atomicAdd(&cnt[c], 1);
-                atomicMin(&first[c], (int)e);
-            }
+        if (e < AC && sc[k] >= thr) {
+            const int c = (int)(e % (unsigned)C);
+            pos[k] = atomicAdd(&cnt[c], 1);
+            atomicMin(&first[c], (int)e);
         }
     }
     __syncthreads();
@@ -158,167 +293,297 @@ det_threshold_kernel(const float *__restrict__ cls, const float *__restrict__ bo
 #pragma unroll
     for (int k = 0; k < DET_EPT; ++k) {
         if (pos[k] < 0) continue;
-        const long long e = e0 + k * 256 + threadIdx.x;
-        const int c = (int)(e % C);
-        const int a = (int)(e / C);
+        const unsigned e = e0 + k * 256 + threadIdx.x;
+        const int a = (int)(e / (unsigned)C);
+        const int c = (int)(e - (unsigned)a * (unsigned)C);
         const long long slot = (long long)(b * C + c) * A + gbase[c] + pos[k];
         w.keys[slot] = ((u64)__float_as_uint(sc[k]) << 32) | (u64)(0xffffffffu - (unsigned)a);
         w.cbox[slot] = corners(*reinterpret_cast<const f32x4 *>(boxes + ((long long)b * A + a) * 4));
     }
 }
 
-// 2. per-(image,class) NMS (detection.py:499-524): one block per bucket.
-//    Keys live in registers (NMS_R per thread, slot = r*512 + tid) when the bucket fits, so a
-//    round is: register max -> block max -> owner publishes the winner's box -> kill sweep whose
-//    box loads are issued in independent batches (the sweep is latency-, not bandwidth-bound).
-//    Buckets larger than 1024*NMS_R fall back to keys in global memory.
+// 2. per-(image,class) NMS (detection.py:499-524): one block per bucket, processed in SCORE BANDS.
+//    Greedy NMS consumes candidates in descending score order and stops after max_out picks, so a
+//    bucket of n candidates (17 k per bucket in the benchmark) rarely needs more than its top few
+//    hundred.  A 2048-bin histogram of the score bits (monotone in the score) cuts the bucket into
+//    bands of NMS_BAND_FIRST (x4 per band) .. NMS_BAND candidates, highest scores first; a band is gathered into LDS
+//    (keys + boxes), sorted, and resolved by greedy_sorted(); the next band is only touched when
+//    fewer than max_out boxes have been selected.
+//    Exact: every candidate of a later band scores below every candidate of an earlier one, and ties
+//    inside a band are broken by the index carried in the key.  A single bin with more than NMS_BAND
+//    candidates (many identical scores) falls back to rounds over global memory for that bin.
 constexpr int NMS_T = 512;
-constexpr int NMS_R = 48;
+constexpr int NMS_BINS = 2048;
+constexpr int NMS_BAND = 4096;
+constexpr int NMS_BAND_FIRST = 256;    // target size of the first band; single-band buckets: n <= NMS_BAND_MIN
+constexpr int NMS_BAND_MIN = 1024;
+constexpr int NMS_U = 8;        // keys loaded per thread before any is consumed (memory-level parallelism)
+
+struct NmsShared {
+    int hist[NMS_BINS + 1];   // histogram, then in place its suffix sums: hist[b] = #candidates in bins >= b
+    int wsum[NMS_T / 64];
+    u64 red[17];
+    GreedyShared greedy;
+    int lo, band_n, sel_slot;
+};
 
 __global__ void __launch_bounds__(NMS_T)
-det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr) {
-    __shared__ u64 red[17];
-    __shared__ f32x4 sel_box;
+det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf) {
+    extern __shared__ __align__(16) unsigned char nms_smem[];
+    f32x4 *bbox = reinterpret_cast<f32x4 *>(nms_smem);                                   // [NMS_BAND]
+    f32x4 *sel = bbox + NMS_BAND;                                                        // [max_out]
+    u64 *bkey = reinterpret_cast<u64 *>(sel + max_out);                                  // [NMS_BAND]
+    unsigned short *bidx = reinterpret_cast<unsigned short *>(bkey + NMS_BAND);          // [NMS_BAND]
+    NmsShared *sh = reinterpret_cast<NmsShared *>(bidx + NMS_BAND);
     const int bucket = blockIdx.x;
     const int n = w.bucket_count[bucket];
     u64 *keys = w.keys + (long long)bucket * A;
     const f32x4 *cb = w.cbox + (long long)bucket * A;
-    int picked = 0;
-    if (n <= NMS_T * NMS_R) {
-        u64 k[NMS_R];
+    const int tid = threadIdx.x;
+
+    // monotone score -> bin map over [min_conf, 1]
+    const unsigned lo_bits = min_conf > 0.f ? __float_as_uint(min_conf) : 0u;
+    const unsigned range = 0x3F800000u > lo_bits ? 0x3F800000u - lo_bits + 1u : 1u;
+    int shift = 0;
+    while ((range >> shift) >= (unsigned)NMS_BINS) ++shift;
+    auto bin_of = [&](u64 k) {
+        const unsigned sb = (unsigned)(k >> 32);
+        const unsigned d = sb > lo_bits ? sb - lo_bits : 0u;
+        const unsigned bn = d >> shift;
+        return (int)(bn < (unsigned)NMS_BINS ? bn : NMS_BINS - 1);
+    };
+
+    const bool single_band = n <= NMS_BAND_MIN;
+    if (!single_band) {
+        for (int i = tid; i < NMS_BINS; i += NMS_T) sh->hist[i] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += NMS_T * NMS_U) {          // NMS_U independent loads in flight per thread
+            u64 kk[NMS_U];
 #pragma unroll
-        for (int r = 0; r < NMS_R; ++r) {
-            const int i = r * NMS_T + threadIdx.x;
-            k[r] = i < n ? keys[i] : 0;
+            for (int u = 0; u < NMS_U; ++u) {
+                const int i = i0 + u * NMS_T + tid;
+                kk[u] = i < n ? keys[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < NMS_U; ++u)
+                if (kk[u] != 0) atomicAdd(&sh->hist[bin_of(kk[u])], 1);
         }
-        for (; picked < max_out; ++picked) {
-            u64 best = 0;
+        __syncthreads();
+        // suffix sums in place (thread t owns bins 4t..4t+3): the band search below is then one parallel
+        // compare per bin instead of a serial walk over (mostly empty) bins
+        static_assert(NMS_BINS == 4 * NMS_T, "one thread per 4 bins");
+        const int lane = tid & 63, wave = tid >> 6;
+        int loc[4], own = 0;
 #pragma unroll
-            for (int r = 0; r < NMS_R; ++r) best = k[r] > best ? k[r] : best;
-            best = block_max_u64(best, red);
-            if (best == 0) break;  // uniform: nothing alive
+        for (int u = 0; u < 4; ++u) { loc[u] = sh->hist[4 * tid + u]; own += loc[u]; }
+        int v = own;                                     // inclusive suffix over the wave's threads
 #pragma unroll
-            for (int r = 0; r < NMS_R; ++r)
-                if (k[r] == best) { sel_box = cb[r * NMS_T + threadIdx.x]; k[r] = 0; }
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(v, off, 64);
+            if (lane + off < 64) v += o;
+        }
+        if (lane == 0) sh->wsum[wave] = v;
+        __syncthreads();
+        for (int w2 = wave + 1; w2 < NMS_T / 64; ++w2) v += sh->wsum[w2];
+        int run = v - own;
+#pragma unroll
+        for (int u = 3; u >= 0; --u) { run += loc[u]; sh->hist[4 * tid + u] = run; }
+        if (tid == 0) sh->hist[NMS_BINS] = 0;
+    }
+    __syncthreads();
+
+    int picked = 0;
+    int hi = NMS_BINS;                                   // exclusive upper bin of the next band
+    int band_target = NMS_BAND_FIRST;                    // grows x4 per band: most buckets finish in the first
+    while (picked < max_out && hi > 0 && n > 0) {
+        // ---- choose the band [lo, hi): top bins until it holds >= band_target, never more than NMS_BAND
+        int lo = 0, bn = n;
+        if (!single_band) {
+            if (tid == 0) sh->lo = 0;
             __syncthreads();
-            const f32x4 sb = sel_box;
-            if (threadIdx.x == 0)
-                w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+            const int below = sh->hist[hi];              // candidates in the bands already processed
+            const int want = below + band_target;
 #pragma unroll
-            for (int r0 = 0; r0 < NMS_R; r0 += 8) {
-                if (r0 * NMS_T >= n) break;                       // uniform
-                f32x4 bx[8];
+            for (int u = 0; u < 4; ++u) {                // the unique bin where the suffix count crosses `want`
+                const int b = 4 * tid + u;
+                if (b < hi && sh->hist[b] >= want && sh->hist[b + 1] < want) sh->lo = b;
+            }
+            __syncthreads();
+            lo = sh->lo;                                 // 0 when fewer than band_target candidates are left
+            bn = sh->hist[lo] - below;
+            // never more than NMS_BAND: give up the crossing bin unless it is the band's only non-empty one
+            if (bn > NMS_BAND && lo + 1 < hi && sh->hist[lo + 1] - below > 0) {
+                ++lo;
+                bn = sh->hist[lo] - below;
+            }
+            __syncthreads();
+        }
+        if (bn == 0) { hi = lo; continue; }
+        if (bn <= NMS_BAND) {
+            // ---- gather the band into LDS (any order), pad to a power of two, sort by key
+            int P = 64;
+            while (P < bn) P <<= 1;
+            if (tid == 0) sh->band_n = 0;
+            for (int j = bn + tid; j < P; j += NMS_T) { bkey[j] = 0; bidx[j] = 0; }
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += NMS_T * NMS_U) {
+                u64 kk[NMS_U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {                     // 8 independent loads in flight
-                    const int i = (r0 + u) * NMS_T + threadIdx.x;
-                    bx[u] = (k[r0 + u] != 0) ? cb[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NMS_U; ++u) {
+                    const int i = i0 + u * NMS_T + tid;
+                    kk[u] = i < n ? keys[i] : 0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (k[r0 + u] != 0 && iou_tf(bx[u], sb) > iou_thr) k[r0 + u] = 0;
-            }
-        }
-    } else {
-        __shared__ int sel_slot;
-        for (; picked < max_out; ++picked) {
-            u64 best = 0;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const u64 kk = keys[i];
-                best = kk > best ? kk : best;
-            }
-            best = block_max_u64(best, red);
-            if (best == 0) break;
-            for (int i = threadIdx.x; i < n; i += blockDim.x)
-                if (keys[i] == best) sel_slot = i;
-            __syncthreads();
-            const f32x4 sb = cb[sel_slot];
-            if (threadIdx.x == 0)
-                w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const u64 kk = keys[i];
-                if (kk == 0) continue;
-                if (i == sel_slot || iou_tf(cb[i], sb) > iou_thr) keys[i] = 0;
+                for (int u = 0; u < NMS_U; ++u) {
+                    const u64 k = kk[u];
+                    const int b = single_band ? lo : bin_of(k);
+                    const bool hit = k != 0 && b >= lo && b < hi;
+                    const u64 hits = __ballot(hit);      // one LDS atomic per wave, not per candidate
+                    if (hits == 0) continue;
+                    const int leader = __ffsll((long long)hits) - 1;
+                    int wbase = 0;
+                    if ((tid & 63) == leader) wbase = atomicAdd(&sh->band_n, __popcll(hits));
+                    wbase = __builtin_amdgcn_readlane(wbase, __builtin_amdgcn_readfirstlane(leader));
+                    if (hit) {
+                        const int p = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0));
+                        bkey[p] = k;
+                        bidx[p] = (unsigned short)p;
+                        bbox[p] = cb[i0 + u * NMS_T + tid];
+                    }
+                }
             }
             __syncthreads();
+            bitonic_sort_desc<true>(bkey, bidx, P);
+            picked = greedy_sorted<true>(bkey, bidx, bbox, bn, sel, picked, max_out, iou_thr, &sh->greedy,
+                                         [&](int slot_out, u64 key, int) {
+                                             w.s1_anchor[(long long)bucket * max_out + slot_out] =
+                                                 (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+                                         });
+        } else {
+            // ---- one bin larger than the LDS band (ties en masse): rounds over global memory for that bin
+            for (int i = tid; i < n; i += NMS_T) {       // suppression by earlier selections first
+                const u64 k = keys[i];
+                if (k == 0) continue;
+                const int b = bin_of(k);
+                if (b < lo || b >= hi) continue;
+                const f32x4 bi = cb[i];
+                for (int q = 0; q < picked; ++q)
+                    if (iou_gt(bi, sel[q], iou_thr)) { keys[i] = 0; break; }
+            }
+            __syncthreads();
+            while (picked < max_out) {
+                u64 best = 0;
+                for (int i = tid; i < n; i += NMS_T) {
+                    const u64 k = keys[i];
+                    if (k == 0) continue;
+                    const int b = bin_of(k);
+                    if (b >= lo && b < hi && k > best) best = k;
+                }
+                best = block_max_u64(best, sh->red);
+                if (best == 0) break;
+                for (int i = tid; i < n; i += NMS_T)
+                    if (keys[i] == best) { sh->sel_slot = i; keys[i] = 0; }
+                __syncthreads();
+                const f32x4 sb = cb[sh->sel_slot];
+                if (tid == 0) {
+                    sel[picked] = sb;
+                    w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+                }
+                for (int i = tid; i < n; i += NMS_T) {
+                    const u64 k = keys[i];
+                    if (k == 0) continue;
+                    const int b = bin_of(k);
+                    if (b >= lo && b < hi && iou_gt(cb[i], sb, iou_thr)) keys[i] = 0;
+                }
+                ++picked;
+                __syncthreads();
+            }
         }
+        hi = lo;
+        band_target = band_target * 4 < NMS_BAND ? band_target * 4 : NMS_BAND;
     }
-    if (threadIdx.x == 0) w.s1_count[bucket] = picked;
+    if (tid == 0) w.s1_count[bucket] = picked;
 }
 
 // 3+4. per-image cross-class NMS (detection.py:531-555) + result rows (:557-563) + -1 padding.
 //      one block per image; candidates (<= C*max_out) live in LDS.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 det_nms_image_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, float *__restrict__ proposed,
                      int *__restrict__ counts, int *__restrict__ kept, int A, int C, int max_out, float iou_thr) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ u64 red[17];
     __shared__ int order[64];     // bucket ranks (C <= 64)
     __shared__ int base[65];
+    __shared__ GreedyShared greedy;
     const int b = blockIdx.x;
     const int cap2 = C * max_out;
-    f32x4 *cbx = reinterpret_cast<f32x4 *>(smem);
-    u64 *keys = reinterpret_cast<u64 *>(smem + (size_t)cap2 * 16);
-    int *anch = reinterpret_cast<int *>(smem + (size_t)cap2 * 24);
-    int *clsid = reinterpret_cast<int *>(smem + (size_t)cap2 * 28);
+    int P2 = 64;
+    while (P2 < cap2) P2 <<= 1;
+    f32x4 *cbx = reinterpret_cast<f32x4 *>(smem);                          // [cap2]
+    f32x4 *sel = cbx + cap2;                                               // [max_out]
+    u64 *keys = reinterpret_cast<u64 *>(sel + max_out);                    // [P2]
+    int *anch = reinterpret_cast<int *>(keys + P2);                        // [cap2]
+    int *clsid = anch + cap2;                                              // [cap2]
+    int *pick = clsid + cap2;                                              // [max_out]
 
     // tf.unique order of the image's (image,class) ids = ascending first-occurrence key
+    __shared__ int bfirst[64], bcount[64];
+    if (threadIdx.x < C) {                                  // one parallel round trip for the bucket headers
+        bfirst[threadIdx.x] = w.bucket_first[b * C + threadIdx.x];
+        bcount[threadIdx.x] = w.s1_count[b * C + threadIdx.x];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         int idx[64];
         for (int c = 0; c < C; ++c) idx[c] = c;
         for (int i = 1; i < C; ++i) {  // insertion sort by bucket_first
             const int v = idx[i];
-            const int kv = w.bucket_first[b * C + v];
+            const int kv = bfirst[v];
             int j = i - 1;
-            while (j >= 0 && w.bucket_first[b * C + idx[j]] > kv) { idx[j + 1] = idx[j]; --j; }
+            while (j >= 0 && bfirst[idx[j]] > kv) { idx[j + 1] = idx[j]; --j; }
             idx[j + 1] = v;
         }
         int off = 0;
         for (int r = 0; r < C; ++r) {
             order[r] = idx[r];
             base[r] = off;
-            off += w.s1_count[b * C + idx[r]];
+            off += bcount[idx[r]];
         }
         base[C] = off;
     }
     __syncthreads();
     const int n = base[C];
-    for (int r = 0; r < C; ++r) {
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {      // flat over the image's candidates: one load chain
+        int r = 0;
+        while (base[r + 1] <= p) ++r;
         const int c = order[r];
-        const int cnt = base[r + 1] - base[r];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const int a = w.s1_anchor[((long long)b * C + c) * max_out + i];
-            const int p = base[r] + i;
-            const float s = cls[((long long)b * A + a) * C + c];
-            keys[p] = ((u64)__float_as_uint(s) << 32) | (u64)(0xffffffffu - (unsigned)p);
-            cbx[p] = corners(*reinterpret_cast<const f32x4 *>(boxes + ((long long)b * A + a) * 4));
-            anch[p] = a;
-            clsid[p] = c;
-        }
+        const int a = w.s1_anchor[((long long)b * C + c) * max_out + (p - base[r])];
+        const float s = cls[((long long)b * A + a) * C + c];
+        keys[p] = ((u64)__float_as_uint(s) << 32) | (u64)(0xffffffffu - (unsigned)p);
+        cbx[p] = corners(*reinterpret_cast<const f32x4 *>(boxes + ((long long)b * A + a) * 4));
+        anch[p] = a;
+        clsid[p] = c;
     }
     __syncthreads();
-    int picked = 0;
-    for (; picked < max_out; ++picked) {
-        u64 best = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) best = keys[i] > best ? keys[i] : best;
-        best = block_max_u64(best, red);
-        if (best == 0) break;
-        const int p = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
-        const f32x4 sb = cbx[p];
-        if (threadIdx.x < 6) {
-            const int a = anch[p], c = clsid[p];
-            float v;
-            if (threadIdx.x < 4) v = boxes[((long long)b * A + a) * 4 + threadIdx.x];
-            else if (threadIdx.x == 4) v = (float)c;
-            else v = __uint_as_float((unsigned)(best >> 32));
-            proposed[((long long)b * max_out + picked) * 6 + threadIdx.x] = v;
-            if (kept && threadIdx.x < 2)
-                kept[((long long)b * max_out + picked) * 2 + threadIdx.x] = threadIdx.x == 0 ? a : c;
-        }
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            if (keys[i] == 0) continue;
-            if (i == p || iou_tf(cbx[i], sb) > iou_thr) keys[i] = 0;
-        }
-        __syncthreads();
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = n + threadIdx.x; i < P; i += blockDim.x) keys[i] = 0;
+    __syncthreads();
+    bitonic_sort_desc<false>(keys, nullptr, P);
+    // picks are recorded in LDS (re-using the dead tail of `sel` is not possible: it is live) ...
+    const int picked = greedy_sorted<false>(
+        keys, nullptr, cbx, n, sel, 0, max_out, iou_thr, &greedy, [&](int slot_out, u64, int p) { pick[slot_out] = p; });
+    // ... and the result rows (:557-563) are written by the whole block afterwards
+    for (int i = threadIdx.x; i < picked * 6; i += blockDim.x) {
+        const int r = i / 6, f = i - r * 6;
+        const int p = pick[r];
+        const int a = anch[p], c = clsid[p];
+        float v;
+        if (f < 4) v = boxes[((long long)b * A + a) * 4 + f];
+        else if (f == 4) v = (float)c;
+        else v = cls[((long long)b * A + a) * C + c];
+        proposed[((long long)b * max_out + r) * 6 + f] = v;
+        if (kept && f < 2) kept[((long long)b * max_out + r) * 2 + f] = f == 0 ? a : c;
     }
     for (int i = picked * 6 + threadIdx.x; i < max_out * 6; i += blockDim.x)
         proposed[(long long)b * max_out * 6 + i] = -1.f;
@@ -445,8 +710,10 @@ extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *box
     ML_REQUIRE(B > 0 && A > 0 && C > 0 && C <= 64 && max_out > 0, "detection_proposal: bad dims (C <= 64)");
     ML_REQUIRE((long long)A * C < (1ll << 31), "detection_proposal: A*C overflows the first-occurrence key");
     ML_REQUIRE(ml_aligned16(boxes) && (((uintptr_t)workspace) & 255) == 0, "detection_proposal: alignment");
-    const long long lds2 = (long long)C * max_out * 32;
-    ML_REQUIRE(lds2 <= 64 * 1024, "detection_proposal: C*max_out = %d exceeds the stage-2 LDS capacity 2048", C * max_out);
+    ML_REQUIRE(C * max_out <= 2048, "detection_proposal: C*max_out = %d exceeds the stage-2 LDS capacity 2048", C * max_out);
+    long long p2 = 64;
+    while (p2 < (long long)C * max_out) p2 <<= 1;
+    const long long lds2 = (long long)C * max_out * 24 + (long long)max_out * 20 + p2 * 8;
     long long bytes = 0;
     DetWs w = det_ws_carve(workspace, B, A, C, max_out, &bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -455,8 +722,22 @@ extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *box
     const long long per_image = (long long)A * C;
     hipLaunchKernelGGL(det_threshold_kernel, dim3((unsigned)((per_image + DET_EPB - 1) / DET_EPB), B), dim3(256), 0, s,
                        cls_pred, boxes, w, A, C, min_confidence);
-    hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(NMS_T), 0, s, w, A, max_out, nms_iou);
-    hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(256), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
+    {
+        const size_t nms_lds = (size_t)NMS_BAND * 16 + (size_t)max_out * 16 + (size_t)NMS_BAND * 10 + sizeof(NmsShared);
+        ML_REQUIRE(nms_lds <= 160 * 1024, "detection_proposal: max_out %d too large for the NMS LDS budget", max_out);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_bucket_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                ml_set_error("detection_proposal: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return ML_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(NMS_T), nms_lds, s, w, A, max_out, nms_iou, min_confidence);
+    }
+    hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(512), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
                        kept, A, C, max_out, post_iou);
     ML_CHECK_LAUNCH("detection_proposal");
     return ML_OK;

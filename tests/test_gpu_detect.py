@@ -80,6 +80,53 @@ def test_detection_proposal_bit_exact(B, hw, frac, thr):
         assert np.all(kept[b, counts[b]:] == -1)
 
 
+def _check_single_image(cls, boxes, nms_iou, post_iou):
+    from masklab_hip import ops
+    ref, kept_ref = O.detection_proposal(cls, boxes, 0.5, nms_iou, post_iou, 100)
+    prop, counts, kept = ops.detection_proposal(dev(cls), dev(boxes), 0.5, nms_iou, post_iou, 100, want_kept=True)
+    prop, counts, kept = host(prop), host(counts), host(kept)
+    np.testing.assert_array_equal(kept[0, :counts[0]], kept_ref[:, 1:])
+    np.testing.assert_array_equal(prop[:, :ref.shape[1]], ref)
+    return int(counts[0])
+
+
+def test_detection_proposal_many_equal_scores_falls_back_exactly():
+    """> 4096 candidates with the SAME score in one (image,class) bucket: one histogram bin overflows the
+    LDS band, so the kernel takes its global-memory rounds for that bin; the result still equals the
+    oracle's (lower index first among equal scores) and the higher-scored band before it is honoured."""
+    pri = _anchors(256, 256)
+    A = pri.shape[0]
+    cls = np.zeros((1, A, 5), np.float32)
+    rng = np.random.default_rng(3)
+    same = rng.choice(A, 6000, replace=False)
+    cls[0, same, 2] = 0.625
+    hi = rng.choice(A, 50, replace=False)
+    cls[0, hi, 2] = (0.7 + 0.25 * (rng.permutation(50) + 0.5) / 50).astype(np.float32)
+    loc = (rng.normal(size=(1, A, 4)) * 0.2).astype(np.float32)
+    boxes = O.restore_boxes(loc, pri[None])
+    assert _check_single_image(cls, boxes, 0.4, 0.6) > 20
+
+
+def test_detection_proposal_multi_band_bucket():
+    """one bucket with 20 k distinct-score candidates (five LDS bands) and weak suppression by IoU but
+    strong suppression by duplicates: 3 of 4 candidates are exact copies of a higher-scored box, so the
+    first band yields < 100 picks and later bands are reached with pre-suppression by earlier picks."""
+    pri = _anchors(512, 512)
+    A = pri.shape[0]
+    rng = np.random.default_rng(8)
+    cls = np.zeros((1, A, 5), np.float32)
+    idx = rng.choice(A, 20000, replace=False)
+    cls[0, idx, 1] = (0.5 + 0.5 * (rng.permutation(20000) + 0.5) / 20000).astype(np.float32)
+    boxes = O.restore_boxes(np.zeros((1, A, 4), np.float32), pri[None]).copy()
+    # collapse the candidates onto 60 distinct boxes => at most 60 survivors, found across several bands
+    # 40 of them only among the 15 000 best scores, the other 20 only below (=> picks from a late band)
+    proto = boxes[0, rng.choice(A, 60, replace=False)]
+    by_score = idx[np.argsort(-cls[0, idx, 1], kind='stable')]
+    boxes[0, by_score[:15000]] = proto[rng.integers(0, 40, 15000)]
+    boxes[0, by_score[15000:]] = proto[rng.integers(40, 60, 5000)]
+    assert _check_single_image(cls, boxes, 0.95, 0.99) == 60
+
+
 def test_detection_proposal_tie_break_lower_index():
     from masklab_hip import ops
     pri = _anchors(128, 128)
