@@ -186,6 +186,44 @@ int ml_add_f32(float *x, const float *y, int64_t n, void *stream);
 /* fill n floats with v */
 int ml_fill_f32(float *x, float v, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Deploy wrapper either side of the forward (reference engine/retinamasklab.py:598-643) --
+ * SURVEY section 8(f) ranks 1 and 2.
+ * ------------------------------------------------------------------------------------------- */
+#define ML_SMOOTH_MAX_CLASSES 16
+
+/* tf.compat.v1.image.resize_bilinear(align_corners=True) for any channel count: replaces the resize
+ * inside DownSampleInput.call (engine/layers/misc.py:143-154; uint8 or float images, cast to f32
+ * first), ResizeLike on the 3-channel semantic map (retinamasklab.py:628) and the semantic resize of
+ * UpSampleOutput.call (misc.py:190-193).  in: [B,H,W,C] u8 (in_is_u8) or f32.  Writes the f32 result
+ * to out_f32 and/or `value > threshold ? 1 : 0` to out_i32 (either may be NULL), both [B,Ho,Wo,C]. */
+int ml_resize_image_ac(const void *in, int32_t in_is_u8, float *out_f32, int32_t *out_i32, float threshold,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
+
+/* TrimInstances.call (engine/layers/instance.py:258-277) with mold=True, fixed capacity: per image the
+ * rows of roi_boxes [B,N,6] whose class (column 4) != -1 are moved to the front in order, their mask
+ * is the class channel of roi_masks [B,N,mh,mw,C]; out_boxes [B,N,6] / out_masks [B,N,mh,mw] are
+ * -1 padded (MoldBatch, misc.py:231-286) and counts[b] = rows kept.  The reference's dynamic second
+ * axis is max(counts): the caller slices.                                                         */
+int ml_trim_instances_f32(const float *roi_boxes, const float *roi_masks, float *out_boxes, float *out_masks,
+                          int32_t *counts, int32_t B, int32_t N, int32_t mh, int32_t mw, int32_t C, void *stream);
+
+/* UpSampleOutput.call box part (engine/layers/misc.py:178-187): rows (cx,cy,w,h,label,conf) f32 ->
+ * int32 (cx*ratio0, cy*ratio1, w*ratio0, h*ratio1, label, conf*100), truncating like tf.cast.
+ * ratio0 is the HEIGHT ratio and ratio1 the width ratio, as in the reference.                       */
+int ml_upsample_boxes_i32(const float *rows, int32_t *out, int64_t n_rows, float ratio0, float ratio1, void *stream);
+
+/* out[i] = in[i] > threshold ? 1 : 0  (tf.cast(x > 0.5, tf.int32), misc.py:189,194) */
+int ml_threshold_i32(const float *in, int32_t *out, float threshold, int64_t n, void *stream);
+
+/* SemanticSmoothing.call (engine/layers/semantic.py:270-285) for all classes at once: per channel c a
+ * grey opening -- tf.nn.erosion2d then tf.nn.dilation2d with an all-zero kernel_sizes[c]^2 element,
+ * stride 1, SAME (window rows y-(k-1)/2 .. +k-1, positions outside the map ignored) -- times
+ * weights[c]; kernel_sizes[c] <= 0 only applies the weight.  in/out/tmp: three distinct [B,H,W,C]
+ * buffers; kernel_sizes / weights are HOST arrays of C entries (C <= ML_SMOOTH_MAX_CLASSES).        */
+int ml_semantic_smoothing_f32(const float *in, float *out, float *tmp, int32_t B, int32_t H, int32_t W, int32_t C,
+                              const int32_t *kernel_sizes, const float *weights, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ def get_custom_objects():
     names = ["RestoreBoxes", "PriorLayer", "Identity", "FeaturePyramid", "ClassificationSubNet",
              "BoxRegressionSubNet", "MaskSubNet", "NormalizeBoxes", "DetectionProposal", "MoldBatch",
              "MaskDistribute", "PyramidRoiAlign", "ResizeLike", "AtrousSeparableConv2D", "ASPPNetwork",
-             "SegmentationSubNet", "SqueezeExcite", "MobileSeparableConv2D"]
+             "SegmentationSubNet", "SqueezeExcite", "MobileSeparableConv2D", "DownSampleInput", "UpSampleOutput",
+             "TrimInstances", "SemanticSmoothing"]
     reg = {n: getattr(L, n) for n in names}
     reg["BackBonePreProcess"] = BackBonePreProcess
     reg["GroupNormalization"] = GroupNormalization

@@ -63,6 +63,11 @@ SIGNATURES = {
     "ml_roi_crop_resize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp]),
     "ml_add_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_fill_f32": (C.c_int, [_vp, _f32, _i64, _vp]),
+    "ml_resize_image_ac": (C.c_int, [_vp, _i32, _vp, _vp, _f32] + [_i32] * 6 + [_vp]),
+    "ml_trim_instances_f32": (C.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
+    "ml_upsample_boxes_i32": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "ml_threshold_i32": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
+    "ml_semantic_smoothing_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 4 + [_vp, _vp, _vp]),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 from .detection import *  # noqa: F401,F403
 from .detection import (BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, FeaturePyramid,
                         NormalizeBoxes, PriorLayer, RestoreBoxes)
-from .instance import MaskDistribute, MaskSubNet, PyramidRoiAlign
-from .misc import Identity, MobileSeparableConv2D, MoldBatch, ReLU, ResizeLike, SqueezeExcite
-from .semantic import ASPPNetwork, AtrousSeparableConv2D, SegmentationSubNet
+from .instance import MaskDistribute, MaskSubNet, PyramidRoiAlign, TrimInstances
+from .misc import (DownSampleInput, Identity, MobileSeparableConv2D, MoldBatch, ReLU, ResizeLike, SqueezeExcite,
+                   UpSampleOutput)
+from .semantic import ASPPNetwork, AtrousSeparableConv2D, SegmentationSubNet, SemanticSmoothing

@@ -131,3 +131,32 @@ class MaskSubNet(Layer, _TowerMixin):
             "expand_ratio": self.expand_ratio, "use_squeeze_excite": self.use_squeeze_excite,
             "squeeze_ratio": self.squeeze_ratio, "groups": self.groups})
         return config
+
+
+class TrimInstances(Layer):
+    """Drop the -1 padded RoIs and keep each RoI's own class channel (reference instance.py:258-286):
+    rows with class != -1, in tf.where (row-major) order; mask = roi_masks[b, r, :, :, class];
+    mold=True re-groups per image with -1 padding (MoldBatch) -> ([B,n,6], [B,n,h,w]), n = the
+    largest per-image count; mold=False returns the flat rows ([R,6], [R,h,w])."""
+
+    def __init__(self, mold=True, max_batch_size=64, **kwargs):
+        self.mold = mold
+        self.max_batch_size = max_batch_size
+        super().__init__(**kwargs)
+        self.last_counts = None
+
+    def call(self, inputs, **kwargs):
+        roi_boxes, roi_masks = inputs[0], inputs[1]
+        boxes, masks, counts = ops.trim_instances(roi_boxes, roi_masks)
+        self.last_counts = counts
+        host_counts = counts.cpu()                       # the dynamic output shape needs the count on the host
+        if self.mold:
+            n = max(1, int(host_counts.max())) if host_counts.numel() else 1
+            return boxes[:, :n].contiguous(), masks[:, :n].contiguous()
+        keep = torch.arange(boxes.shape[1], device=boxes.device)[None, :] < counts[:, None]
+        return boxes[keep], masks[keep]
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"mold": self.mold, "max_batch_size": self.max_batch_size})
+        return config

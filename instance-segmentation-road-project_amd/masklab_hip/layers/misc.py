@@ -1,5 +1,7 @@
 """Misc layers of the hot path -- drop-ins for reference engine/layers/misc.py
-(Identity :206-210, ResizeLike :296-319, SqueezeExcite :24-54, MoldBatch :213-293)."""
+(Identity :206-210, ResizeLike :296-319, SqueezeExcite :24-54, MoldBatch :213-293) and of the
+deploy wrapper either side of it (DownSampleInput :143-154, UpSampleOutput :169-196)."""
+import numpy as np
 import torch
 
 from .. import ops
@@ -174,3 +176,48 @@ class MoldBatch(Layer):
         config = super().get_config()
         config.update({"max_batch_size": self.max_batch_size})
         return config
+
+
+class DownSampleInput(Layer):
+    """Resize the input to the model resolution, keeping the aspect ratio (reference misc.py:135-161):
+    ratio = min(target_h / h, target_w / w) in float32, size = int32(ratio * h, ratio * w) (truncated),
+    tf.compat.v1.image.resize_bilinear(align_corners=True) of the float32-cast image."""
+
+    def __init__(self, target_size=(540, 960), **kwargs):
+        self.target_size = target_size
+        super().__init__(**kwargs)
+
+    def output_size(self, input_h, input_w):
+        f = np.float32
+        ratio = min(f(self.target_size[0]) / f(input_h), f(self.target_size[1]) / f(input_w))
+        return int(f(ratio) * f(input_h)), int(f(ratio) * f(input_w))      # tf.cast(float32 -> int32) truncates
+
+    def call(self, inputs, **kwargs):
+        oh, ow = self.output_size(int(inputs.shape[1]), int(inputs.shape[2]))
+        return ops.resize_image_ac(inputs, oh, ow)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"target_size": self.target_size})
+        return config
+
+
+class UpSampleOutput(Layer):
+    """Restore the outputs to the input resolution (reference misc.py:164-196).
+    inputs = [roi_box, roi_mask, semantic_output], target= the original images.  Returns int32
+    (roi_box, roi_mask, semantic_output): boxes scaled (cx, w by the HEIGHT ratio and cy, h by the
+    width ratio -- the reference's own mix-up, misc.py:180-183 -- conf * 100), masks > 0.5, semantic map
+    resized bilinear(align_corners=True) to the input size then > 0.5."""
+
+    def call(self, inputs, **kwargs):
+        target_node = kwargs.get('target')
+        roi_box, roi_mask, semantic_output = inputs[0], inputs[1], inputs[2]
+        f = np.float32
+        src = (f(semantic_output.shape[1]), f(semantic_output.shape[2]))
+        dst = (f(target_node.shape[1]), f(target_node.shape[2]))
+        ratio_shape = (dst[0] / src[0], dst[1] / src[1])
+        boxes = ops.upsample_boxes(roi_box, ratio_shape[0], ratio_shape[1])
+        masks = ops.threshold_i32(roi_mask, 0.5)
+        semantic = ops.resize_image_ac(semantic_output, int(target_node.shape[1]), int(target_node.shape[2]),
+                                       threshold=0.5)
+        return boxes, masks, semantic

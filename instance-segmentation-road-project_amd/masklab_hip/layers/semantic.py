@@ -180,3 +180,30 @@ class SegmentationSubNet(Layer, _TowerMixin):
             "use_squeeze_excite": self.use_squeeze_excite, "squeeze_ratio": self.squeeze_ratio,
             "groups": self.groups})
         return config
+
+
+class SemanticSmoothing(Layer):
+    """Label-map post-processing (reference semantic.py:258-292): grey opening -- tf.nn.erosion2d then
+    tf.nn.dilation2d with an all-zero kernel_size x kernel_size element, SAME -- times `weight`;
+    kernel_size <= 0 only applies the weight.  One instance handles every channel of its input with the
+    same (kernel_size, weight), like the reference's per-class tf.split; `smooth_classes` below runs the
+    whole split -> smooth -> concat of retinamasklab.py:619-627 in one call."""
+
+    def __init__(self, kernel_size=10, weight=1., **kwargs):
+        self.kernel_size = kernel_size
+        self.weight = weight
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        n_classes = int(inputs.shape[-1])
+        return ops.semantic_smoothing(inputs, [self.kernel_size] * n_classes, [self.weight] * n_classes)
+
+    @staticmethod
+    def smooth_classes(seg_pred, kernel_sizes, weights):
+        """tf.split(seg_pred, n) -> SemanticSmoothing(kernel, weight) per class -> tf.concat."""
+        return ops.semantic_smoothing(seg_pred, list(kernel_sizes), list(weights))
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"kernel_size": self.kernel_size, "weight": self.weight})
+        return config

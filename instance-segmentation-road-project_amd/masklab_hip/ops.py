@@ -267,6 +267,10 @@ def resize_bilinear_ac(x, oh, ow, add=None, out=None, out_coff=0):
     lib = _lib.load()
     _require_dev(x, "x")
     B, H, W, Cc = x.shape
+    if Cc % 4 != 0:                    # e.g. the 3-class semantic map: scalar kernel, no add / concat view
+        if add is not None or out is not None:
+            raise RuntimeError("resize_bilinear_ac: add=/out= need a channel count that is a multiple of 4")
+        return resize_image_ac(x, oh, ow)
     if out is None:
         out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device)
         out_coff = 0
@@ -370,3 +374,77 @@ def fill_(x, v):
     lib = _lib.load()
     _lib.check(lib.ml_fill_f32(_ptr(x), float(v), x.numel(), _stream()), "ml_fill_f32")
     return x
+
+
+# ----------------------------------------------------------------------------- deploy wrapper
+def resize_image_ac(x, oh, ow, threshold=None):
+    """ml_resize_image_ac: bilinear(align_corners=True) of a [B,H,W,C] uint8 / float32 tensor, any C.
+    threshold=None -> float32 result; else int32 `value > threshold`."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    if x.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError(f"resize_image_ac: uint8 or float32 input, got {x.dtype}")
+    B, H, W, Cc = x.shape
+    out_f = out_i = None
+    if threshold is None:
+        out_f = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device)
+    else:
+        out_i = torch.empty((B, oh, ow, Cc), dtype=torch.int32, device=x.device)
+    with _Prof("resize_image", 0, x.numel() * x.element_size() + 4 * B * oh * ow * Cc):
+        _lib.check(lib.ml_resize_image_ac(_ptr(x), int(x.dtype == torch.uint8), _ptr(out_f), _ptr(out_i),
+                                          float(threshold if threshold is not None else 0.0), B, H, W, Cc, oh, ow,
+                                          _stream()), "ml_resize_image_ac")
+    return out_f if threshold is None else out_i
+
+
+def trim_instances(roi_boxes, roi_masks):
+    """ml_trim_instances_f32 -> (boxes [B,N,6], masks [B,N,mh,mw], counts [B] int32), fixed capacity."""
+    lib = _lib.load()
+    _require_dev(roi_boxes, "roi_boxes")
+    _require_dev(roi_masks, "roi_masks")
+    B, N, six = roi_boxes.shape
+    if six != 6 or roi_masks.dim() != 5 or tuple(roi_masks.shape[:2]) != (B, N):
+        raise ValueError(f"trim_instances: roi_boxes [B,N,6] / roi_masks [B,N,h,w,C] expected, got "
+                         f"{tuple(roi_boxes.shape)} / {tuple(roi_masks.shape)}")
+    _, _, mh, mw, Cc = roi_masks.shape
+    out_b = torch.empty((B, N, 6), dtype=torch.float32, device=roi_boxes.device)
+    out_m = torch.empty((B, N, mh, mw), dtype=torch.float32, device=roi_boxes.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=roi_boxes.device)
+    with _Prof("trim_instances", 0, 4 * (roi_boxes.numel() * 2 + out_m.numel() * 2)):
+        _lib.check(lib.ml_trim_instances_f32(_ptr(roi_boxes), _ptr(roi_masks), _ptr(out_b), _ptr(out_m), _ptr(counts),
+                                             B, N, mh, mw, Cc, _stream()), "ml_trim_instances_f32")
+    return out_b, out_m, counts
+
+
+def upsample_boxes(rows, ratio0, ratio1):
+    lib = _lib.load()
+    _require_dev(rows, "rows")
+    out = torch.empty(rows.shape, dtype=torch.int32, device=rows.device)
+    _lib.check(lib.ml_upsample_boxes_i32(_ptr(rows), _ptr(out), rows.numel() // 6, float(ratio0), float(ratio1),
+                                         _stream()), "ml_upsample_boxes_i32")
+    return out
+
+
+def threshold_i32(x, threshold=0.5):
+    lib = _lib.load()
+    _require_dev(x, "x")
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    _lib.check(lib.ml_threshold_i32(_ptr(x), _ptr(out), float(threshold), x.numel(), _stream()), "ml_threshold_i32")
+    return out
+
+
+def semantic_smoothing(x, kernel_sizes, weights):
+    """ml_semantic_smoothing_f32: per-class grey opening (erosion -> dilation, flat k x k) times weight."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    B, H, W, Cc = x.shape
+    if len(kernel_sizes) != Cc or len(weights) != Cc:
+        raise ValueError(f"semantic_smoothing: {Cc} classes need {Cc} kernel sizes and weights")
+    ks = (C.c_int32 * Cc)(*[int(k) for k in kernel_sizes])
+    ws = (C.c_float * Cc)(*[float(w) for w in weights])
+    out = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    with _Prof("semantic_smoothing", 0, 4 * x.numel() * 8):
+        _lib.check(lib.ml_semantic_smoothing_f32(_ptr(x), _ptr(out), _ptr(tmp), B, H, W, Cc, ks, ws, _stream()),
+                   "ml_semantic_smoothing_f32")
+    return out

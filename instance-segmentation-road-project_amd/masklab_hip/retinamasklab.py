@@ -1,6 +1,7 @@
 """Model build API -- drop-in for the inference half of reference engine/retinamasklab.py:
 build_backbone_network :19-37, build_detection_network :40-112, build_instance_network :115-157,
-build_semantic_network :160-198, construct_inference_network :420-495, find_layer_name :646-649.
+build_semantic_network :160-198, construct_inference_network :420-495, find_layer_name :646-649,
+and the deploy wrapper of load_masklab_inference_model_from_h5 :598-643 (DeployModel below).
 Same function names, argument meaning and return structure; the returned model runs eagerly on
 the MI355X kernels.  Training-only pieces (construct_trainer_network, losses, dataset) are out of
 scope of the accelerated path.
@@ -11,9 +12,9 @@ import torch
 from . import backbone
 from . import keras_like as K
 from .config import ModelConfiguration
-from .layers import (ASPPNetwork, BoxRegressionSubNet, ClassificationSubNet, DetectionProposal,
-                     FeaturePyramid, MaskDistribute, MaskSubNet, PriorLayer, PyramidRoiAlign,
-                     RestoreBoxes, SegmentationSubNet)
+from .layers import (ASPPNetwork, BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, DownSampleInput,
+                     FeaturePyramid, MaskDistribute, MaskSubNet, PriorLayer, PyramidRoiAlign, ResizeLike,
+                     RestoreBoxes, SegmentationSubNet, SemanticSmoothing, TrimInstances, UpSampleOutput)
 from .prior import PriorBoxes
 
 VERBOSE = False
@@ -261,6 +262,76 @@ def construct_masklab_networks(config: ModelConfiguration, with_trainer=False):
                                             semantic_networks=semantic_networks,
                                             instance_networks=instance_networks)
     return None, inference
+
+
+class DeployModel(K.Layer):
+    """The non-serving `Model(images -> (detection, instance, semantic))` that reference
+    load_masklab_inference_model_from_h5 assembles around the inference network (:598-643):
+    DownSampleInput(config.postprocess.resolution) -> inference model -> TrimInstances(mold=True),
+    per-class SemanticSmoothing + ResizeLike(target=downsampled) -> UpSampleOutput(target=images).
+    All three outputs are int32: detection [B,n,6] (cx,cy,w,h,label,conf*100 at input resolution),
+    instance [B,n,h,w] (0/1), semantic [B,H,W,classes] (0/1)."""
+
+    def __init__(self, configuration, inference_model, name='inference'):
+        super().__init__(name=name)
+        if inference_model.output_names != ['cls_pred', 'loc_pred', 'roi_boxes', 'roi_masks', 'seg_pred']:
+            raise ValueError("the deploy wrapper unpacks five outputs (reference :608): it needs the detection, "
+                             "instance and semantic heads")
+        post = configuration.postprocess
+        if len(post.smoothing_kernel_sizes) != len(post.smoothing_weights):
+            raise ValueError("postprocess.smoothing_kernel_sizes and smoothing_weights differ in length")
+        self.configuration = configuration
+        self.model = inference_model
+        self.down_sample = DownSampleInput(post.resolution)
+        self.trim = TrimInstances(mold=True)
+        self.smoothing = [SemanticSmoothing(kernel_size=k, weight=w)
+                          for k, w in zip(post.smoothing_kernel_sizes, post.smoothing_weights)]
+        self.resize_like = ResizeLike()
+        self.up_sample = UpSampleOutput()
+        self.output_names = ['detection', 'instance', 'semantic']
+        self.built = True
+
+    def call(self, images, **kwargs):
+        if not isinstance(images, torch.Tensor):
+            images = torch.as_tensor(np.asarray(images))
+        if self.model.device is None:
+            raise RuntimeError("DeployModel: load weights into the inference model first")
+        images = images.to(self.model.device).contiguous()
+        downsampled = self.down_sample(images)                                     # :607
+        _, _, box_pred, mask_pred, seg_pred = self.model(downsampled)              # :608
+        detection_pred, instance_pred = self.trim([box_pred, mask_pred])           # :614-615
+        n_split = len(self.smoothing)
+        n_cls = int(seg_pred.shape[-1])
+        if n_cls % n_split:
+            raise ValueError(f"tf.split: {n_cls} semantic classes do not split into {n_split} parts (:619)")
+        rep = n_cls // n_split
+        post_semantics = SemanticSmoothing.smooth_classes(                         # :619-627 in one launch group
+            seg_pred, [l.kernel_size for l in self.smoothing for _ in range(rep)],
+            [l.weight for l in self.smoothing for _ in range(rep)])
+        semantic_pred = self.resize_like(post_semantics, target=downsampled)       # :628
+        return self.up_sample([detection_pred, instance_pred, semantic_pred], target=images)   # :634-635
+
+    def predict(self, images, **kwargs):
+        outs = self.call(images, **kwargs)
+        torch.cuda.synchronize(self.model.device)
+        return [o.cpu().numpy() for o in outs]
+
+
+def construct_deploy_network(configuration: ModelConfiguration, inference_model):
+    """Wrap an inference model like reference :598-643 (serving=False)."""
+    return DeployModel(configuration, inference_model)
+
+
+def load_masklab_inference_model_from_weights(weights, config: ModelConfiguration, device="cuda"):
+    """Counterpart of reference load_masklab_inference_model_from_h5 (:498-643) for a name-keyed
+    weight dict / .npz (see tools/convert_keras_h5.py for the h5 -> npz step): builds the networks
+    from `config`, loads the weights and returns the deploy model."""
+    if isinstance(weights, str):
+        with np.load(weights) as z:
+            weights = {k: z[k] for k in z.files}
+    _, inference = construct_masklab_networks(config)
+    inference.load_weights(weights, device)
+    return construct_deploy_network(config, inference)
 
 
 def find_layer_name(re_format, model):

@@ -526,3 +526,63 @@ def inference_forward(config, weights, images, dtype=np.float32, literal_groups=
         internals["aspp"] = aspp
         outs.append(seg)
     return (outs, internals) if return_internals else outs
+
+
+# ----------------------------------------------------------------------------- deploy wrapper
+def down_sample_input(images, target_size=(540, 960)):
+    """DownSampleInput.call, engine/layers/misc.py:143-154."""
+    x = np.asarray(images).astype(F32)                                   # :144 tf.cast(inputs, float32)
+    _, ih, iw, _ = x.shape
+    ratio = min(F32(target_size[0]) / F32(ih), F32(target_size[1]) / F32(iw))          # :150
+    oh, ow = int(F32(ratio) * F32(ih)), int(F32(ratio) * F32(iw))                      # :151 cast -> int32
+    return T.resize_bilinear_align_corners(x, oh, ow)                                  # :153
+
+
+def trim_instances(roi_boxes, roi_masks, mold=True, max_batch_size=64):
+    """TrimInstances.call, engine/layers/instance.py:258-277."""
+    B = roi_boxes.shape[0]
+    cls = roi_boxes[:, :, -2]
+    idx = np.argwhere(cls != -1)                                          # :263 tf.where, row-major
+    ci = cls[idx[:, 0], idx[:, 1]].astype(np.int64)                       # :265
+    tm = np.transpose(roi_masks, (0, 1, 4, 2, 3))[idx[:, 0], idx[:, 1], ci]            # :268
+    tb = roi_boxes[idx[:, 0], idx[:, 1]]                                  # :269
+    if not mold:
+        return tb, tm
+    return (T.mold_batch(tb, idx[:, 0], B, None), T.mold_batch(tm, idx[:, 0], B, None))
+
+
+def semantic_smoothing(x, kernel_size=10, weight=1.0):
+    """SemanticSmoothing.call, engine/layers/semantic.py:270-285."""
+    if kernel_size > 0:
+        k = np.zeros((kernel_size, kernel_size, x.shape[-1]), F32)        # :273
+        return T.dilation2d(T.erosion2d(x, k), k) * F32(weight)           # :275-284
+    return x * F32(weight)
+
+
+def up_sample_output(roi_box, roi_mask, semantic_output, target_hw):
+    """UpSampleOutput.call, engine/layers/misc.py:169-196."""
+    src = np.asarray(semantic_output.shape[1:3], F32)
+    dst = np.asarray(target_hw, F32)
+    ratio = dst / src                                                     # :176
+    cx, cy, w, h, label, confs = [roi_box[..., i] for i in range(6)]
+    box = np.stack([(cx * ratio[0]).astype(np.int32), (cy * ratio[1]).astype(np.int32),   # :179-182 (sic)
+                    (w * ratio[0]).astype(np.int32), (h * ratio[1]).astype(np.int32),
+                    label.astype(np.int32), (confs * F32(100)).astype(np.int32)], axis=-1)
+    mask = (roi_mask > 0.5).astype(np.int32)                              # :188
+    sem = T.resize_bilinear_align_corners(semantic_output.astype(F32), int(target_hw[0]), int(target_hw[1]))
+    return box, mask, (sem > 0.5).astype(np.int32)                        # :193-194
+
+
+def deploy_forward(config, weights, images, **kw):
+    """The non-serving model of load_masklab_inference_model_from_h5, engine/retinamasklab.py:598-643:
+    DownSampleInput -> inference model -> TrimInstances + per-class SemanticSmoothing + ResizeLike
+    -> UpSampleOutput.  Returns int32 (detection, instance, semantic)."""
+    images = np.asarray(images)
+    down = down_sample_input(images, config.postprocess.resolution)       # :607
+    _, _, box_pred, mask_pred, seg_pred = inference_forward(config, weights, down, **kw)   # :608
+    det, inst = trim_instances(box_pred, mask_pred, mold=True)            # :614-615
+    ks, ws = config.postprocess.smoothing_kernel_sizes, config.postprocess.smoothing_weights
+    parts = np.split(seg_pred, len(ks), axis=-1)                          # :619-620
+    post = np.concatenate([semantic_smoothing(t, k, w_) for t, k, w_ in zip(parts, ks, ws)], axis=-1)
+    sem = T.resize_bilinear_align_corners(post, down.shape[1], down.shape[2])          # :628
+    return up_sample_output(det, inst, sem, images.shape[1:3])            # :634-635

@@ -316,3 +316,32 @@ def mold_batch(inputs, batch_indices, batch_size, max_batch_size=32):
         rows = inputs[batch_indices == b]
         out[b, :len(rows)] = rows
     return out
+
+
+def dilation2d(x, kernel, padding="SAME"):
+    """tf.nn.dilation2d, strides = rates = 1, SAME (call site: semantic.py:283):
+    out[b,y,x,c] = max_{dy,dx} in[b, y + dy - pad_top, x + dx - pad_left, c] + kernel[dy,dx,c],
+    pad_top = (kh-1)//2, pad_left = (kw-1)//2 (Appendix A 'same' rule); positions outside the input
+    do not take part in the max (TF's kernel skips them)."""
+    assert padding == "SAME"
+    B, H, W, C = x.shape
+    kh, kw, kc = kernel.shape
+    assert kc == C
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    out = np.full(x.shape, -np.inf, x.dtype)
+    for dy in range(kh):
+        for dx in range(kw):
+            oy, ox = dy - pt, dx - pl                      # out[y,x] sees in[y+oy, x+ox]
+            y0, y1 = max(0, -oy), min(H, H - oy)
+            x0, x1 = max(0, -ox), min(W, W - ox)
+            if y0 >= y1 or x0 >= x1:
+                continue
+            cand = x[:, y0 + oy:y1 + oy, x0 + ox:x1 + ox, :] + kernel[dy, dx].astype(x.dtype)
+            out[:, y0:y1, x0:x1, :] = np.maximum(out[:, y0:y1, x0:x1, :], cand)
+    return out
+
+
+def erosion2d(x, kernel, padding="SAME"):
+    """tf.nn.erosion2d (call site: semantic.py:279).  TF 1.x defines it by duality (nn_ops.py):
+    negative(dilation2d(negative(value), reverse(kernel, [0, 1]), padding))."""
+    return -dilation2d(-x, kernel[::-1, ::-1], padding)

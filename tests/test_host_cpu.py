@@ -153,3 +153,91 @@ def test_forward_golden_is_reproducible_from_seeds(golden_dir):
     np.testing.assert_array_equal(internals["kept"], g["kept"])
     for name, o in zip(["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"], outs):
         np.testing.assert_allclose(o, g[name], rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- deploy wrapper
+def test_deploy_layers_config_and_registry():
+    import masklab_hip as M
+    from masklab_hip import layers as L
+    reg = M.get_custom_objects()
+    for name in ("DownSampleInput", "UpSampleOutput", "TrimInstances", "SemanticSmoothing"):
+        assert reg[name] is getattr(L, name)
+    assert L.DownSampleInput().get_config()["target_size"] == (540, 960)          # reference misc.py:141
+    assert L.TrimInstances().get_config()["mold"] is True and L.TrimInstances().get_config()["max_batch_size"] == 64
+    c = L.SemanticSmoothing().get_config()
+    assert c["kernel_size"] == 10 and c["weight"] == 1.0                          # reference semantic.py:263
+    d = L.DownSampleInput((540, 960))
+    assert d.output_size(1080, 1920) == (540, 960)
+    assert d.output_size(720, 960) == (540, 720)            # aspect ratio kept, truncated
+    assert d.output_size(400, 640) == (540, 864)            # small inputs are enlarged the same way
+
+
+def test_deploy_layers_refuse_cpu_tensors():
+    import torch
+    from masklab_hip import layers as L
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.DownSampleInput()(torch.zeros((1, 8, 8, 3), dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.SemanticSmoothing(3)(torch.zeros((1, 8, 8, 3)))
+
+
+class _FakeH5(dict):
+    """the slice of the h5py mapping protocol the converter relies on"""
+
+    def __init__(self, *a, attrs=None, **k):
+        super().__init__(*a, **k)
+        self.attrs = attrs or {}
+
+
+def _fake_keras_file(weights, nested_prefix=""):
+    by_layer = {}
+    for name, arr in weights.items():
+        by_layer.setdefault(name.split("/")[0], []).append((name, arr))
+    root = _FakeH5(attrs={"layer_names": [k.encode() for k in by_layer]})
+    for lname, items in by_layer.items():
+        grp = _FakeH5(attrs={"weight_names": [(nested_prefix + n + ":0").encode() for n, _ in items]})
+        for n, arr in items:
+            node = grp
+            parts = (nested_prefix + n + ":0").split("/")
+            for part in parts[:-1]:
+                node = node.setdefault(part, _FakeH5())
+            node[parts[-1]] = arr
+        root[lname] = grp
+    return _FakeH5({"model_weights": root})
+
+
+def test_keras_h5_converter_walks_and_matches_names():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "convert_keras_h5", os.path.join(os.path.dirname(__file__), "..", "tools", "convert_keras_h5.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = "mobilenet"
+    _, model = R.construct_masklab_networks(cfg)
+    w = model.init_weights(1)
+    specs = {k: tuple(v.shape) for k, v in model.weight_specs().items()}
+    # a model.save file, plus an optimizer-ish extra tensor that must be reported as unused
+    f = _fake_keras_file(dict(w, **{"training_only_layer/kernel": np.zeros((2, 2), np.float32)}))
+    got = conv.collect_h5_weights(f)
+    assert set(got) == set(w) | {"training_only_layer/kernel"}
+    matched, report = conv.match_to_model(got, specs)
+    assert report["missing"] == [] and report["shape_mismatch"] == []
+    assert report["unexpected"] == ["training_only_layer/kernel"]
+    for k in w:
+        np.testing.assert_array_equal(matched[k], w[k])
+    # save_weights layout (no model_weights group)
+    got2 = conv.collect_h5_weights(f["model_weights"])
+    assert set(got2) == set(got)
+    # an outer model scope in the file ("inference/<name>") is matched by unique suffix
+    scoped, rep = conv.match_to_model({"inference/" + k: v for k, v in w.items()}, specs)
+    assert rep["missing"] == [] and set(scoped) == set(w)
+    # a missing tensor and a wrong shape are reported, not silently skipped
+    bad = dict(got)
+    first = sorted(w)[0]
+    del bad[first]
+    second = sorted(w)[1]
+    bad[second] = np.zeros((1,), np.float32)
+    _, rep = conv.match_to_model(bad, specs)
+    assert rep["missing"] == [first] and rep["shape_mismatch"][0][0] == second

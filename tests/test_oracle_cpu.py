@@ -275,3 +275,66 @@ def test_preprocess_modes():
                                (img - np.asarray([123.68, 116.779, 103.939], np.float32)) / 127.5, rtol=1e-6)
     np.testing.assert_allclose(O.backbone_preprocess(img, rgb=False, mean_shift=False, normalize=2),
                                img[..., ::-1] / 127.5 - 1, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- deploy wrapper
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 10, 11])
+def test_morphology_against_scipy(k):
+    """Independent restatement: scipy.ndimage min/max filters with the window shifted the way TF's SAME
+    padding places it (rows y-(k-1)//2 .. y-(k-1)//2+k-1) and +-inf outside the map."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    x = np.random.default_rng(k).normal(size=(2, 13, 17, 3)).astype(np.float32)
+    z = np.zeros((k, k, 3), np.float32)
+    org = 0 if k % 2 else -1
+    want_d = ndi.maximum_filter(x, size=(1, k, k, 1), mode="constant", cval=-np.inf, origin=(0, org, org, 0))
+    want_e = ndi.minimum_filter(x, size=(1, k, k, 1), mode="constant", cval=np.inf, origin=(0, org, org, 0))
+    np.testing.assert_array_equal(T.dilation2d(x, z), want_d)
+    np.testing.assert_array_equal(T.erosion2d(x, z), want_e)
+
+
+def test_dilation_with_nonzero_structuring_element():
+    """hand-checked 1-D case: in = [1, 5, 2], element [0, 10, 0] -> max(in[x-1], in[x]+10, in[x+1])"""
+    x = np.array([1, 5, 2], np.float32).reshape(1, 1, 3, 1)
+    k = np.array([0, 10, 0], np.float32).reshape(1, 3, 1)
+    np.testing.assert_array_equal(T.dilation2d(x, k).ravel(), [11, 15, 12])
+    # erosion by duality with the element reversed: min(in[x-1]-0, in[x]-10, in[x+1]-0)
+    np.testing.assert_array_equal(T.erosion2d(x, k).ravel(), [-9, -5, -8])
+
+
+def test_semantic_smoothing_is_an_opening():
+    x = np.random.default_rng(0).random((1, 20, 20, 2)).astype(np.float32)
+    y = O.semantic_smoothing(x, 3, 1.0)
+    assert np.all(y <= x)                                           # an opening never exceeds its input
+    np.testing.assert_array_equal(O.semantic_smoothing(y, 3, 1.0), y)     # and is idempotent
+    np.testing.assert_array_equal(O.semantic_smoothing(x, 0, 2.0), x * np.float32(2.0))
+
+
+def test_down_sample_input_size_rule():
+    for (h, w), want in (((1080, 1920), (540, 960)), ((720, 960), (540, 720)), ((400, 640), (540, 864)),
+                         ((1000, 3000), (320, 960))):
+        out = O.down_sample_input(np.zeros((1, h, w, 3), np.uint8), (540, 960))
+        assert out.shape[1:3] == want and out.dtype == np.float32
+
+
+def test_trim_instances_orders_and_pads():
+    boxes = np.full((2, 4, 6), -1, np.float32)
+    boxes[0, 0] = [10, 10, 4, 4, 2, 0.9]
+    boxes[0, 2] = [20, 20, 4, 4, 0, 0.8]                            # a hole at row 1: order must be kept
+    masks = np.arange(2 * 4 * 2 * 2 * 3, dtype=np.float32).reshape(2, 4, 2, 2, 3)
+    b, m = O.trim_instances(boxes, masks)
+    assert b.shape == (2, 2, 6) and m.shape == (2, 2, 2, 2)
+    np.testing.assert_array_equal(b[0], boxes[0, [0, 2]])
+    np.testing.assert_array_equal(m[0, 0], masks[0, 0, :, :, 2])
+    np.testing.assert_array_equal(m[0, 1], masks[0, 2, :, :, 0])
+    assert np.all(b[1] == -1) and np.all(m[1] == -1)
+
+
+def test_up_sample_output_axis_quirk():
+    """cx and w are scaled by the HEIGHT ratio, cy and h by the width ratio (misc.py:180-183)."""
+    box = np.array([[[10, 10, 4, 4, 1, 0.876], [-1, -1, -1, -1, -1, -1]]], np.float32)
+    mask = np.zeros((1, 2, 2, 2), np.float32)
+    sem = np.zeros((1, 10, 20, 1), np.float32)
+    b, m, s = O.up_sample_output(box, mask, sem, (30, 40))           # ratios: height 3, width 2
+    np.testing.assert_array_equal(b[0, 0], [30, 20, 12, 8, 1, 87])
+    np.testing.assert_array_equal(b[0, 1], [-3, -2, -3, -2, -1, -100])
+    assert s.shape == (1, 30, 40, 1) and s.dtype == np.int32
