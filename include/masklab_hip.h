@@ -32,6 +32,7 @@ extern "C" {
 #define ML_E_NOGPU  (-3)   /* no gfx950 device visible                        */
 
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
+enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1 };
 
 int ml_version(void);                 /* ABI version, currently 1                         */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
@@ -68,6 +69,11 @@ typedef struct ml_conv2d_desc {
     int32_t group_cin_step; /* grouped 3x3: input-channel offset per 32-wide N block; else 0  */
     int32_t shuffle2x2;     /* 1: Conv2DTranspose epilogue, column = (a*2+b)*cout_real + o    */
     int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32                    */
+    int32_t math;           /* ML_MATH_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products);
+                               ML_MATH_F16: operands rounded to fp16 on their way into LDS,
+                               v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5);
+                               tensors in HBM stay fp32 either way                              */
+    int32_t reserved0;      /* must be 0                                                      */
     int64_t out_bstride;    /* floats between images in `out`; 0 = Ho*Wo*out_cstride (dense).
                                Lets a level's head write straight into the concatenated
                                [B, A, classes] prediction (detection.py:210-212 Reshape+Concatenate) */

@@ -44,6 +44,9 @@ extern "C" int ml_debug_read_stamps(unsigned long long *host) {
 namespace {
 
 constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
+constexpr int LDS_LD_H = 40; // f16 math: halves per staged row (32 + 8 pad: 80-byte rows, conflict-free b128 reads)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // (out-of-image taps: the buffer loads below return zeros for out-of-range offsets -- no post-load select,
 // which would force an s_waitcnt vmcnt before the MFMA block)
@@ -133,16 +136,20 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
     return ok;
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+// F16 = true: the "fp16 MFMA path" (BASELINE config 5): activations and weights stay fp32 in HBM, are
+// rounded to fp16 (RNE) on their way into LDS, and the contraction runs on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation -- 2 instructions of 32 cycles per 32-deep chunk and tile pair instead of 16 of 64.
+// Everything outside the K loop (addressing, prefetch pieces, epilogue, split-K) is shared.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool F16>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const MultiArgs args) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
     constexpr int B_LD = BN / 32;
-    constexpr int BUF = (BM + BN) * LDS_LD;
+    constexpr int BUF = F16 ? (BM + BN) * LDS_LD_H / 2 : (BM + BN) * LDS_LD;    // floats per staging buffer
     constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
-    static_assert(BM * C_LD <= 2 * BUF, "epilogue tile must fit in the staging buffers");
+    static_assert(F16 || BM * C_LD <= 2 * BUF, "epilogue tile must fit in the staging buffers");
     extern __shared__ __align__(16) float lds[];
     STAMP1(0);
 
@@ -299,6 +306,21 @@ conv_mfma_kernel(const MultiArgs args) {
         piece_end();
     };
     auto store_chunk = [&](int buf) {
+        if constexpr (F16) {
+            _Float16 *As = reinterpret_cast<_Float16 *>(lds + buf * BUF);
+            _Float16 *Bs = As + BM * LDS_LD_H;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const f16x4 hv = {(_Float16)areg[i][0], (_Float16)areg[i][1], (_Float16)areg[i][2], (_Float16)areg[i][3]};
+                *reinterpret_cast<f16x4 *>(As + (ld_row + 32 * i) * LDS_LD_H + ld_c) = hv;
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const f16x4 hv = {(_Float16)breg[i][0], (_Float16)breg[i][1], (_Float16)breg[i][2], (_Float16)breg[i][3]};
+                *reinterpret_cast<f16x4 *>(Bs + (ld_row + 32 * i) * LDS_LD_H + ld_c) = hv;
+            }
+            return;
+        }
         float *As = lds + buf * BUF;
         float *Bs = As + BM * LDS_LD;
 #pragma unroll
@@ -319,8 +341,9 @@ conv_mfma_kernel(const MultiArgs args) {
 
     const int r = lane & 31;
     const int h = lane >> 5;
-    const int a_off = (wm * TM * 32 + r) * LDS_LD + h * 4;
-    const int b_off = BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
+    const int a_off = F16 ? (wm * TM * 32 + r) * LDS_LD_H + h * 8 : (wm * TM * 32 + r) * LDS_LD + h * 4;
+    const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8
+                          : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
 
     STAMP1(1);
     if (kc_begin < kc_end) {
@@ -350,6 +373,41 @@ conv_mfma_kernel(const MultiArgs args) {
         constexpr int NMFMA = 16 * TM * TN;
         constexpr int GAP = NMFMA >= 4 * NPIECE ? 2 : 1;     // pieces ride early so the loads have the rest of the block to land
         int placed = 0;
+        if constexpr (F16) {
+            // lane (r, h) holds A[row r][k = 16 ks + 8 h + j], j = 0..7 (one ds_read_b128), B likewise
+            const _Float16 *baseh = reinterpret_cast<const _Float16 *>(base);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[TM], b[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    a[mi] = *reinterpret_cast<const f16x8 *>(baseh + a_off + mi * 32 * LDS_LD_H + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    b[ni] = *reinterpret_cast<const f16x8 *>(baseh + b_off + ni * 32 * LDS_LD_H + ks * 16);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                        if (placed < NPIECE) {               // one prefetch piece per MFMA
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (placed < A_LD) piece_a(placed);
+                            else if (placed < A_LD + B_LD) piece_b(placed - A_LD, kc_next);
+                            else piece_end();
+                            ++placed;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)                 // what did not fit between the MFMAs
+                if (q >= placed) {
+                    if (q < A_LD) piece_a(q);
+                    else if (q < A_LD + B_LD) piece_b(q - A_LD, kc_next);
+                    else piece_end();
+                }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f32x4 a[TM], b[TN];
@@ -549,15 +607,17 @@ int choose_splits(long long tiles, int chunks) {
     return s < 2 ? 1 : s;
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool F16>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
-    constexpr int LDS_BYTES0 = 2 * (BM + BN) * LDS_LD * 4;
+    constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : 2 * (BM + BN) * LDS_LD * 4;
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
+    constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     static int lds_pad = -1;
     if (lds_pad < 0) { const char *e = getenv("MASKLAB_CONV_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }   // experiment knob
     const int LDS_BYTES = LDS_BYTES0 + lds_pad;
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN>;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -637,13 +697,22 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void 
         const int t = pick_tile(descs[i].cout, descs[i].tile);
         if (i == 0) t0 = t;
         ML_REQUIRE(t == t0, "conv2d: all problems of one launch must use the same tile shape");
+        ML_REQUIRE(descs[i].math == descs[0].math, "conv2d: all problems of one launch must use the same math mode");
     }
+    ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (descs[0].math == ML_MATH_F16) {
+        switch (t0) {
+            case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s);
+            case 2: return launch_multi<2, 2, 2, 1, true>(descs, n, workspace, workspace_bytes, s);
+            default: return launch_multi<4, 1, 1, 1, true>(descs, n, workspace, workspace_bytes, s);
+        }
+    }
     switch (t0) {
-        case 1: return launch_multi<2, 2, 2, 2>(descs, n, workspace, workspace_bytes, s);
-        case 2: return launch_multi<2, 2, 2, 1>(descs, n, workspace, workspace_bytes, s);
-        default: return launch_multi<4, 1, 1, 1>(descs, n, workspace, workspace_bytes, s);
+        case 1: return launch_multi<2, 2, 2, 2, false>(descs, n, workspace, workspace_bytes, s);
+        case 2: return launch_multi<2, 2, 2, 1, false>(descs, n, workspace, workspace_bytes, s);
+        default: return launch_multi<4, 1, 1, 1, false>(descs, n, workspace, workspace_bytes, s);
     }
 }
 

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
         ("res_cstride", C.c_int32), ("res_coff", C.c_int32),
         ("act", C.c_int32), ("group_cin_step", C.c_int32), ("shuffle2x2", C.c_int32),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32),
         ("out_bstride", C.c_int64),
     ]
 

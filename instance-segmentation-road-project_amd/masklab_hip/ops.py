@@ -40,6 +40,20 @@ class _Prof:
         return False
 
 
+# Arithmetic of the dense (MFMA) convolutions: "f32" = exact fp32 products (the default; configs 1-4),
+# "f16" = the fp16 MFMA path of BASELINE config 5 (operands rounded to fp16, fp32 accumulation; tensors
+# stay fp32).  Process-wide switch, read when a conv is launched; set it through set_conv_math().
+CONV_MATH = "f32"
+_MATH_CODE = {"f32": 0, "f16": 1}
+
+
+def set_conv_math(mode):
+    global CONV_MATH
+    if mode not in _MATH_CODE:
+        raise ValueError(f"conv math must be one of {sorted(_MATH_CODE)}, got {mode!r}")
+    CONV_MATH = mode
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -124,6 +138,7 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
+    d.math, d.reserved0 = _MATH_CODE[CONV_MATH], 0
     M = B * Ho * Wo
     real_cin = p.span if p.cpp_shift == 30 else 3
     nbytes = 4 * (B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + M * p.cout + p.cout * p.k_real
@@ -133,7 +148,8 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
 
 
 def _conv_kernel_name(p):
-    return "conv_mfma_128x%d%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile), "_grouped" if p.group_cin_step else "")
+    return "conv_mfma_128x%d%s%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile),
+                                     "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH == "f16" else "")
 
 
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,

@@ -28,8 +28,8 @@ def test_shared_library_exports_every_header_symbol():
 def test_conv_desc_struct_matches_header_layout():
     import ctypes
     from masklab_hip import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 26 * 4 + 8       # 5 pointers, 26 int32, 1 int64
-    assert _lib.ConvDesc.out_bstride.offset == 144
+    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 28 * 4 + 8       # 5 pointers, 28 int32, 1 int64
+    assert _lib.ConvDesc.out_bstride.offset == 152 and _lib.ConvDesc.math.offset == 144
 
 
 def test_product_fails_loudly_without_gpu_tensors():
