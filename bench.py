@@ -70,8 +70,8 @@ def measured_traffic(kernel_label):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None
-    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2>", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1>",
-            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1>"}.get(kernel_label)
+    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1",
+            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1"}.get(kernel_label)
     if want is None:
         return None
     try:
