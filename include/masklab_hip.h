@@ -34,7 +34,8 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1 };
 
-int ml_version(void);                 /* ABI version, currently 1                         */
+#define ML_ABI_VERSION 2              /* 2: ml_conv2d_desc gained `math` / `reserved0`     */
+int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
 

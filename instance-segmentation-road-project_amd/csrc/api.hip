@@ -12,7 +12,7 @@ void ml_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int ml_version(void) { return 1; }
+extern "C" int ml_version(void) { return ML_ABI_VERSION; }
 
 extern "C" const char *ml_last_error(void) { return g_err; }
 

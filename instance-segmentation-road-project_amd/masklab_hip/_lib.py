@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
 LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
 
+ABI_VERSION = 2          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -88,6 +89,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.ml_version() != ABI_VERSION:       # e.g. a stale .so from before ml_conv2d_desc changed layout
+        raise RuntimeError(f"masklab_hip: {LIB_PATH} has ABI version {lib.ml_version()}, this package binds "
+                           f"version {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 

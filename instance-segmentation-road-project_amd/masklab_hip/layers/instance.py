@@ -37,14 +37,17 @@ class PyramidRoiAlign(Layer):
         self.max_batch_size = max_batch_size
         super().__init__(**kwargs)
 
-    def crop_levels(self, fmap_outputs, rows, image_hw, has_k, base_size=1.0):
-        """rows: [B,cap,6] proposals (has_k=False) or [B,cap,7] dist_boxes (has_k=True).
-        One device->host read (per-level counts) sizes the molded outputs like the reference."""
-        L = len(fmap_outputs)
-        B = rows.shape[0]
-        if B > 32 and self.max_batch_size is not None:
+    def distribute(self, n_levels, rows, has_k, base_size=1.0):
+        """Enqueue the level assignment + per-level slot lists (no host read)."""
+        if rows.shape[0] > 32 and self.max_batch_size is not None:
             raise ValueError("PyramidRoiAlign: MoldBatch supports at most 32 images per call")
-        slots, lcounts, _ = ops.mask_distribute(rows, L - 1, base_size, has_k=has_k)
+        slots, lcounts, _ = ops.mask_distribute(rows, n_levels - 1, base_size, has_k=has_k)
+        return slots, lcounts
+
+    def crop_distributed(self, fmap_outputs, rows, image_hw, slots, lcounts):
+        """One device->host read (per-level counts) sizes the molded outputs like the reference's dynamic
+        shapes; callers enqueue independent work (the semantic head) before calling this."""
+        B = rows.shape[0]
         n_l = [max(1, int(v)) for v in lcounts.max(dim=0).values.tolist()]     # the single sync
         total = sum(n_l)
         roi_boxes = torch.empty((B, total, 6), dtype=torch.float32, device=rows.device)
@@ -54,6 +57,11 @@ class PyramidRoiAlign(Layer):
                                                  tuple(self.crop_size), image_hw, roi_boxes, off))
             off += n_l[level]
         return roi_fmaps, roi_boxes
+
+    def crop_levels(self, fmap_outputs, rows, image_hw, has_k, base_size=1.0):
+        """rows: [B,cap,6] proposals (has_k=False) or [B,cap,7] dist_boxes (has_k=True)."""
+        slots, lcounts = self.distribute(len(fmap_outputs), rows, has_k, base_size)
+        return self.crop_distributed(fmap_outputs, rows, image_hw, slots, lcounts)
 
     def call(self, inputs, **kwargs):
         fmap_outputs, dist_boxes, images = inputs[0], inputs[1], inputs[2]

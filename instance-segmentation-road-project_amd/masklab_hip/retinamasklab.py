@@ -199,6 +199,14 @@ class InferenceModel(K.Layer):
         feats = bb(images)
         by_name = dict(zip(bb.output_names, feats))
         outputs = []
+
+        def semantic_head():
+            seg_config = cfg.semantic
+            aspp_subnet, seg_subnet = self.semantic_networks
+            aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
+            return seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]])
+
+        seg_pred = None
         if self.detection_networks is not None:
             det_config = cfg.detection
             prior_subnet, fpn_subnet, cls_subnet, loc_subnet = self.detection_networks
@@ -220,17 +228,19 @@ class InferenceModel(K.Layer):
                 if distribute_subnet.max_k + 1 != n_levels:
                     raise ValueError("MaskDistribute.max_k does not match config.instance.max_k")
                 image_hw = (int(images.shape[1]), int(images.shape[2]))
-                roi_fmaps, roi_boxes = pyramid_roi_align.crop_levels(
-                    feature_outputs[:n_levels], proposed, image_hw, has_k=False,
-                    base_size=distribute_subnet.base_size)
+                slots, lcounts = pyramid_roi_align.distribute(n_levels, proposed, has_k=False,
+                                                              base_size=distribute_subnet.base_size)
+                if self.semantic_networks is not None:
+                    # independent of the instance branch: enqueue it BEFORE the host reads the RoI counts,
+                    # so the GPU stays busy while the host waits (same stream, same results)
+                    seg_pred = semantic_head()
+                roi_fmaps, roi_boxes = pyramid_roi_align.crop_distributed(
+                    feature_outputs[:n_levels], proposed, image_hw, slots, lcounts)
                 roi_masks = mask_subnet(roi_fmaps)
                 outputs += [roi_boxes, roi_masks]
                 self.last_detections = dict(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes)
         if self.semantic_networks is not None:
-            seg_config = cfg.semantic
-            aspp_subnet, seg_subnet = self.semantic_networks
-            aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
-            outputs.append(seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]]))
+            outputs.append(seg_pred if seg_pred is not None else semantic_head())
         return outputs
 
     def predict(self, images, **kwargs):
