@@ -1,8 +1,12 @@
 // The reference's chunk-wise GroupNormalization (engine/normalization.py:116-160).
 // Sample n's flat H*W*C vector is cut into G contiguous chunks of L = HWC/G floats;
 //   y = (x - mean_g) / sqrt(var_g + eps) * gamma[j] + beta[j],  j = g*(C/G) + (c mod C/G).
-// HBM-bound: algorithmic traffic = 1 read + 1 write of x (8 B/elt); this implementation reads x
-// twice (stats pass + apply pass) = 12 B/elt, the second read usually served by L2/Infinity Cache.
+// HBM-bound: algorithmic traffic = 1 read + 1 write of x (8 B/elt).
+// Chunks of up to 4096 floats (the small pyramid levels, all RoI maps) take the ONE-PASS kernel: one
+// block per (sample, chunk) holds the chunk in registers (<= 4 float4 per thread), reduces mean and
+// then sum((x-mean)^2) across the block, normalises and writes -- 8 B/elt, one launch.
+// Larger chunks read x twice (stats pass + apply pass) = 12 B/elt, the second read usually served by
+// L2/Infinity Cache:
 //   pass 1: grid (S, N*G): each block sums a slice of one chunk in fp64 (sum, sum of squares)
 //           -> workspace[(n*G+g)*S + s]   (fp64 partials: no cancellation issue in E[x^2]-mean^2)
 //   pass 2: grid (S2, N*G): each block folds the S partials, then normalises its slice.
@@ -12,6 +16,11 @@ namespace {
 
 constexpr int GN_TPB = 256;
 constexpr int GN_MAX_SPLIT = 64;
+// Largest chunk the one-pass (register-resident) kernel takes.  Measured on MI355X: one block per chunk wins
+// while the chunk is small (8x8 .. 32x32 maps, 14x14 RoI maps: 6.3 vs 9.8 us, 8.0 vs 10.2 us); from 64x64x128
+// maps up (chunk 32 768 floats, 128 fat blocks) the sliced two-pass form has the parallelism and is faster
+// (19.8 vs 23.7 us), even though it reads x twice.
+constexpr int GN_ONEPASS_MAX = 4096;
 
 struct GnPlan { int S; long long slice; };
 
@@ -122,6 +131,86 @@ __global__ void gn_apply_kernel(const float *x, float *y, const float *__restric
     }
 }
 
+// ---- one-pass form: the chunk lives in registers.  Block (TPB threads) = one (sample, chunk).
+template <int TPB>
+__device__ __forceinline__ double block_sum(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                       // `red` may still be read from the previous reduction
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) t += red[w];
+    return t;
+}
+
+template <int TPB, int VPT>
+__global__ void __launch_bounds__(TPB)
+gn_onepass_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
+                  const float *__restrict__ beta, int L, int C, int G, float eps, int relu, int out_cs, int out_co) {
+    __shared__ double red[TPB / 64];
+    const int ng = blockIdx.x;
+    const int g = ng % G;
+    const int cg = C / G;
+    const float *p = x + (long long)ng * L;
+    f32x4 v[VPT];
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int i = (k * TPB + threadIdx.x) * 4;
+        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < L) {
+            v[k] = *reinterpret_cast<const f32x4 *>(p + i);
+            sum += ((double)v[k][0] + (double)v[k][1]) + ((double)v[k][2] + (double)v[k][3]);
+        }
+    }
+    const double meand = block_sum<TPB>(sum, red) / (double)L;
+    const float mean = (float)meand;
+    double sq = 0.0;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int i = (k * TPB + threadIdx.x) * 4;
+        if (i < L) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e] - meand; sq += d * d; }
+        }
+    }
+    const double vard = block_sum<TPB>(sq, red) / (double)L;
+    const float rstd = (float)(1.0 / sqrt(vard + (double)eps));
+    const bool dense = (out_cs == C);
+    const long long HWC = (long long)L * G;
+    float *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
+    const long long gbase = (long long)g * L;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int i = (k * TPB + threadIdx.x) * 4;
+        if (i >= L) continue;
+        const int c0 = (int)((gbase + i) % C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int c = c0 + e;
+            if (c >= C) c -= C;
+            const int j = g * cg + (c % cg);
+            float t = (v[k][e] - mean) * rstd;
+            if (gamma) t *= gamma[j];
+            if (beta) t += beta[j];
+            o[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
+        else *reinterpret_cast<f32x4 *>(q + ((gbase + i) / C) * out_cs + c0) = o;
+    }
+}
+
+template <int TPB, int VPT>
+void launch_onepass(const float *x, float *y, const float *gamma, const float *beta, int NG, int L, int C, int G,
+                    float eps, int relu, int out_cs, int out_co, hipStream_t s) {
+    hipLaunchKernelGGL((gn_onepass_kernel<TPB, VPT>), dim3(NG), dim3(TPB), 0, s, x, y, gamma, beta, L, C, G, eps, relu,
+                       out_cs, out_co);
+}
+
 }  // namespace
 
 extern "C" int64_t ml_groupnorm_workspace_bytes(int32_t N, int32_t G) {
@@ -146,7 +235,16 @@ extern "C" int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gam
     hipStream_t s = (hipStream_t)stream;
     double *ws = reinterpret_cast<double *>(workspace);
     const dim3 grid(plan.S, N * G);
-    if (vec4) {
+    if (vec4 && L <= GN_ONEPASS_MAX) {
+        // one pass, chunk in registers: float4-per-thread chosen so that 256 * VPT * 4 >= L
+        const int NG = N * G, Li = (int)L;
+        const int v4 = (Li + 3) / 4;
+#define GN1(TPB, VPT) launch_onepass<TPB, VPT>(x, y, gamma, beta, NG, Li, C, G, eps, relu, out_cstride, out_coff, s)
+        if (v4 <= 256) GN1(256, 1);
+        else if (v4 <= 512) GN1(256, 2);
+        else GN1(256, 4);
+#undef GN1
+    } else if (vec4) {
         hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S, C,
                            G, eps, relu, out_cstride, out_coff);
