@@ -84,17 +84,41 @@ def measured_traffic(kernel_label):
     return None
 
 
-def cpu_baseline(cfg, weights, H, W, max_seconds=60.0):
-    """Oracle forward on the host (1 image).  Returns dict for the JSON line."""
+def cpu_baseline(cfg, weights, img, gpu_outs=None, max_seconds=60.0):
+    """Oracle forward on the host (1 image = rank 0's first bench image).  Returns (cpu_baseline, parity) for the
+    JSON line: the timing, and -- the oracle being the checker -- how the GPU outputs for that image compare."""
     from oracle import masklab as O
-    img = np.random.default_rng(1234).integers(0, 256, (1, H, W, 3), dtype=np.uint8)
+    from oracle import metrics as OM
+    H, W = img.shape[1:3]
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
-    O.inference_forward(cfg, weights, img, literal_groups=False)
+    want = O.inference_forward(cfg, weights, img, literal_groups=False)
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle (not TF-Keras), {dt:.1f}s"}
+    cpu = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle (not TF-Keras), {dt:.1f}s"}
+    parity = None
+    if gpu_outs is not None:
+        names = ["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"]
+        got = dict(zip(names, gpu_outs))
+        ref = dict(zip(names, want))
+        diffs = {}
+        for n in ("cls_pred", "loc_pred", "roi_masks", "seg_pred"):
+            diffs[n] = float(np.abs(got[n].astype(np.float64) - ref[n]).max()) if got[n].shape == ref[n].shape else None
+        same_shape = got["roi_boxes"].shape == ref["roi_boxes"].shape
+        # SURVEY 8(d): precision / recall / F-measure at IoU 0.5 (reference engine/metrics.py:109-165) of the GPU
+        # detections against the oracle's -- the stand-in for "box AP vs Keras ref", 1.0 = same detections
+        pr, rc, fm = OM.detection_iou_metric(got["roi_boxes"], ref["roi_boxes"])
+        parity = {"image": "rank 0, image 0 of the bench batch", "tolerance": 1e-3,
+                  "max_abs_diff": {k: (None if v is None else float(f"{v:.3e}")) for k, v in diffs.items()},
+                  "detections": int((ref["roi_boxes"][..., 4] >= 0).sum()),
+                  "class_ids_and_padding_exact": bool(same_shape and np.array_equal(got["roi_boxes"][..., 4],
+                                                                                    ref["roi_boxes"][..., 4])),
+                  "detection_precision": round(float(pr[0]), 6), "detection_recall": round(float(rc[0]), 6),
+                  "detection_fmeasure": round(float(fm[0]), 6),
+                  "ok": bool(same_shape and all(v is not None and v <= 1e-3 for v in diffs.values())
+                             and np.array_equal(got["roi_boxes"][..., 4], ref["roi_boxes"][..., 4]))}
+    return cpu, parity
 
 
 def main():
@@ -208,9 +232,13 @@ def main():
                         "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, weights, H, W)
+        first = images[:1].contiguous()
+        gpu_first = None
+        if not f16:                     # the fp16 MFMA mode has its own (looser) bar: tests/test_gpu_f16.py
+            gpu_first = [o.cpu().numpy() for o in model(first)]
+        cpu, parity = cpu_baseline(cfg, weights, first.cpu().numpy(), gpu_first)
 
     if rank == 0:
         det = model.last_detections
@@ -231,7 +259,7 @@ def main():
                        "height": H, "width": W, "parallelism": f"dp{world}",
                        "weights": "random init (cls logits x8 so NMS / mask head run at full load)",
                        "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": per_kernel,
         }
         print(json.dumps(line))
     if dist is not None:

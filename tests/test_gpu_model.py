@@ -82,6 +82,14 @@ def test_full_forward_with_detections(bt):
     for b in range(images.shape[0]):
         np.testing.assert_array_equal(kept[b, :counts[b]], kept_ref[kept_ref[:, 0] == b][:, 1:])
     _check(model, got, want)
+    # the reference's own detection metric (engine/metrics.py:109-165), oracle detections as
+    # ground truth -- the stand-in for BASELINE's "box AP vs Keras ref".  Same detections => 1.0.
+    from oracle import metrics as OM
+    names = model.output_names
+    pr, rc, fm = OM.detection_iou_metric(got[names.index("roi_boxes")], want[names.index("roi_boxes")])
+    np.testing.assert_allclose(pr, 1.0, atol=1e-6)
+    np.testing.assert_allclose(rc, 1.0, atol=1e-6)
+    np.testing.assert_allclose(fm, 1.0, atol=1e-6)
 
 
 def test_heads_optional_like_reference():

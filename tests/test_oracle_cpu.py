@@ -338,3 +338,31 @@ def test_up_sample_output_axis_quirk():
     np.testing.assert_array_equal(b[0, 0], [30, 20, 12, 8, 1, 87])
     np.testing.assert_array_equal(b[0, 1], [-3, -2, -3, -2, -1, -100])
     assert s.shape == (1, 30, 40, 1) and s.dtype == np.int32
+
+
+# ----------------------------------------------------------------------------- detection metric
+def test_detection_iou_metric_restatement():
+    from oracle import metrics as M
+    gt = np.full((2, 3, 6), -1, np.float32)
+    gt[0, 0] = [50, 50, 20, 20, 1, 1.0]
+    gt[0, 1] = [150, 50, 40, 20, 2, 1.0]
+    gt[1, 0] = [30, 30, 10, 10, 0, 1.0]
+    pred = np.full((2, 4, 6), -1, np.float32)
+    pred[0, 0] = [51, 50, 20, 20, 1, 0.9]           # IoU 19*20/(800-380) = 0.905 with gt 0
+    pred[0, 1] = [150, 80, 40, 20, 2, 0.8]          # no overlap with gt 1 (30 px lower)
+    pred[0, 2] = [150, 55, 40, 20, 2, 0.7]          # IoU 15*40/(1600-600) = 0.6 with gt 1
+    pred[1, 0] = [30, 30, 10, 10, 0, 0.9]
+    iou = M.calculate_iou(pred[0], gt[0])
+    np.testing.assert_allclose(iou[0, 0], 380.0 / 420.0, rtol=1e-5)
+    np.testing.assert_allclose(iou[2, 1], 600.0 / 1000.0, rtol=1e-5)
+    assert iou[1, 1] == 0
+    p, r, f = M.detection_iou_metric(pred, gt)
+    np.testing.assert_allclose(p, [2 / 3, 1.0], rtol=1e-6)
+    np.testing.assert_allclose(r, [1.0, 1.0], rtol=1e-6)
+    np.testing.assert_allclose(f, [0.8, 1.0], rtol=1e-6)
+    # identical inputs score 1 (up to the metric's epsilon), an image with nothing on either side scores 0
+    p, r, f = M.detection_iou_metric(gt, gt)
+    np.testing.assert_allclose(p, 1.0, rtol=1e-6)
+    empty = np.full((1, 2, 6), -1, np.float32)
+    p, r, f = M.detection_iou_metric(empty, empty)
+    assert p[0] == 0 and r[0] == 0 and f[0] == 0
