@@ -139,13 +139,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MASKLAB_BENCH_REHEARSAL=1: rehearse the N>1 code path on a ONE-GPU box -- every rank on cuda:0, gloo
+    # instead of RCCL.  The numbers of such a run mean nothing; the driver's real runs never set it.
+    rehearsal = os.environ.get("MASKLAB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        import faulthandler
+        faulthandler.enable()
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from masklab_hip import _lib, ops, parallel
     _lib.check(_lib.load().ml_device_check(), "ml_device_check")
@@ -156,11 +166,19 @@ def main():
     cfg, model, weights = build_model(backbone, device)
     images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
 
-    def step():
+    def mark(msg):
+        if rehearsal:
+            print(f"[rehearsal rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    mark("model built")
+
+    def step(collective=True):
         outs = model(images)
-        if world > 1:
+        mark("forward enqueued")
+        if world > 1 and collective:
             det = model.last_detections
             parallel.all_gather_detections(det["proposed"], det["counts"])
+            mark("detections gathered")
         return outs
 
     for _ in range(args.warmup):
@@ -178,7 +196,7 @@ def main():
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -186,7 +204,7 @@ def main():
     per_kernel = None
     if rank == 0 and not args.no_roofline:
         ops.PROFILE = []
-        step()
+        step(collective=False)          # rank 0 only: the other ranks are not in this step, so no collective
         torch.cuda.synchronize(device)
         recs, ops.PROFILE = ops.PROFILE, None
         if args.dump_launches:

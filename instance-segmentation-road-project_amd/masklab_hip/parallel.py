@@ -18,18 +18,31 @@ def shard_batch(images, rank, world_size):
     return images[rank * per:(rank + 1) * per]
 
 
+def _gather0(t, group):
+    """all_gather_into_tensor along axis 0; a GPU tensor on the 'gloo' backend (CPU rehearsal of the N>1
+    path on a one-GPU box) is staged through host memory, RCCL ('nccl') takes it as is."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    stage = t.is_cuda and dist.get_backend(group) == "gloo"
+    src = t.contiguous().cpu() if stage else t.contiguous()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(t.device) if stage else out
+
+
 def all_gather_detections(proposed, counts, group=None):
     """proposed [B_local,cap,6] f32 (-1 padded), counts [B_local] i32 -> ([B_global,cap,6], [B_global]).
+    ONE collective per batch: the int32 counts ride as one extra (bit-cast) float column of the payload.
     Works with backend 'nccl' (= RCCL on ROCm) on GPU tensors and 'gloo' on CPU tensors."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return proposed, counts
-    world = dist.get_world_size(group)
-    out_p = torch.empty((world * proposed.shape[0],) + tuple(proposed.shape[1:]), dtype=proposed.dtype,
-                        device=proposed.device)
-    out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(out_p, proposed.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_c, counts.contiguous(), group=group)
+    B, cap, f = proposed.shape
+    payload = torch.cat([proposed.reshape(B, cap * f),
+                         counts.to(torch.int32).contiguous().view(torch.float32).reshape(B, 1)], dim=1)
+    out = _gather0(payload, group)
+    out_p = out[:, :cap * f].reshape(-1, cap, f).contiguous()
+    out_c = out[:, cap * f].contiguous().view(torch.int32).to(counts.dtype)
     return out_p, out_c
 
 
@@ -38,10 +51,4 @@ def all_gather_outputs(tensors, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return list(tensors)
-    world = dist.get_world_size(group)
-    outs = []
-    for t in tensors:
-        o = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(o, t.contiguous(), group=group)
-        outs.append(o)
-    return outs
+    return [_gather0(t, group) for t in tensors]

@@ -1,0 +1,62 @@
+"""bench.py contract on the GPU box: the JSON line of a small single-rank run, and the N>1 code path
+(rank sharding, the detections all-gather every step, barrier + max-over-ranks timing, rank-0-only
+reporting) rehearsed with two ranks that share the one GPU over gloo (MASKLAB_BENCH_REHEARSAL=1; the
+driver's real multi-GPU runs use RCCL and one GPU per rank).  -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _json_line(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_single_rank():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "resnext50_full_b2_256",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["config"]["workload"] == "resnext50_full_b2_256"
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert 0 < d["roofline"]["frac"] < 1
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["ok"] is True and d["parity"]["detection_fmeasure"] > 0.999
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, MASKLAB_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--workload", "resnext50_full_b2_256", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _json_line(r.stdout)                       # exactly one line: rank 0 reports
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["cpu_baseline"] is None
