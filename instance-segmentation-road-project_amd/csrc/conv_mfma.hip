@@ -187,11 +187,23 @@ conv_mfma_kernel(const MultiArgs args) {
     int a_voff[A_LD];          // byte offset (may be "negative" for halo rows; only used when the tap is valid)
     const int HoWo = p.Ho * p.Wo;
     const int gofs = p.in_coff + nt * p.group_cin_step;
+    // 1x1 / stride-1 / unpadded convs (most of the backbone): every tap of a valid row is inside the image,
+    // so the per-row compares vanish and invalid tail rows rely on their out-of-range base offset.
+    const bool nohalo = (p.KH == 1) && (p.KW == 1) && (p.pad_t == 0) && (p.pad_l == 0) && (p.stride == 1) &&
+                        (p.cpp_shift == 30) && (p.span % 32 == 0);
     STAMP1(9);
+    // Setup and epilogue run beside the co-resident block's MFMA stream, which leaves them about one VALU
+    // issue slot per 64-cycle MFMA (measured: 2 400 cycles for the ~140 instructions below, 9 100 for the
+    // ~150 of the store loop) -- so what counts here is the instruction COUNT, not the latency.
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + ld_row + 32 * i;
-        if (m < M) {
+        if (nohalo) {
+            // output pixel m reads input pixel m: no (b, y, x) decomposition, no divisions
+            a_iy0[i] = 0;
+            a_ix0[i] = 0;
+            a_voff[i] = m < M ? (int)(((long long)m * (long long)p.in_cstride + gofs + ld_c) * 4) : (int)0x80000000;
+        } else if (m < M) {
             const int b = fast_div(m, P.div_howo);
             const int r = m - b * HoWo;
             const int oy = fast_div(r, P.div_wo);
@@ -206,10 +218,6 @@ conv_mfma_kernel(const MultiArgs args) {
             a_voff[i] = (int)0x80000000;       // stays out of range after adding a (small, positive) tap offset
         }
     }
-    // 1x1 / stride-1 / unpadded convs (most of the backbone): every tap of a valid row is inside the image,
-    // so the per-row compares vanish and invalid tail rows rely on their out-of-range base offset.
-    const bool nohalo = (p.KH == 1) && (p.KW == 1) && (p.pad_t == 0) && (p.pad_l == 0) && (p.stride == 1) &&
-                        (p.cpp_shift == 30) && (p.span % 32 == 0);
     // hot descriptor fields in registers: the descriptor lives in kernarg memory and would be
     // re-fetched (s_load + lgkmcnt(0), which also drains LDS) inside the K loop otherwise
     const int pH = p.H, pW = p.W, pKW = p.KW, pdil = p.dil, pspan = p.span, pshift = p.cpp_shift;
@@ -331,16 +339,23 @@ conv_mfma_kernel(const MultiArgs args) {
             *reinterpret_cast<f32x4 *>(Bs + (ld_row + 32 * i) * LDS_LD + ld_c) = breg[i];
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
     const int r = lane & 31;
     const int h = lane >> 5;
+    // Block-uniform: this tile takes the fast epilogue.  Then the bias is not added there (64 VALU adds per
+    // thread) but is what the accumulators start from -- a lane's 16 registers of one 32x32 tile all belong
+    // to ONE output column, so it costs one scalar load per tile column block.
+    const bool fast_blk = direct && out_vec_ok(p) && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID && (p.cout % 4 == 0);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = n0 + wn * TN * 32 + ni * 32 + r;
+        const float b0 = (fast_blk && p.bias && col < p.cout) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b0;
+    }
+
     const int a_off = F16 ? (wm * TM * 32 + r) * LDS_LD_H + h * 8 : (wm * TM * 32 + r) * LDS_LD + h * 4;
     const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8
                           : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
@@ -475,13 +490,11 @@ conv_mfma_kernel(const MultiArgs args) {
         return;
     }
     if (n >= p.cout) return;
-    if (vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID) {
+    if (fast_blk) {
         // fast path (every backbone / tower conv): dense or channel-sliced NHWC destination, float4 lanes,
         // ReLU / ReLU6 / none as a branch-free clamp.  Row pointers advance by a constant stride.
         const float lo = (p.act == ML_ACT_NONE) ? -3.402823466e38f : 0.f;
         const float hi = (p.act == ML_ACT_RELU6) ? 6.f : 3.402823466e38f;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
         const bool late_res = p.residual && !pre_res;
         const size_t cs = p.out_cstride;
         size_t off;
@@ -497,21 +510,36 @@ conv_mfma_kernel(const MultiArgs args) {
 #pragma unroll
         for (int i = 0; i < E_ROWS; ++i)
             tile_v[i] = *reinterpret_cast<const f32x4 *>(lds + (r0 + i * ROWS_PER_PASS) * C_LD + c4);
+        // (the bias is already in the accumulators; the clamp is one v_med3_f32 per element)
+        const bool full = (m0 + BM <= M);            // block-uniform: no per-row range checks
+        if (full && !late_res && !p.out_bstride) {
+            float *op = p.out + off;
+            const size_t step = (size_t)ROWS_PER_PASS * cs;
 #pragma unroll
-        for (int i = 0; i < E_ROWS; ++i) {
-            const int m = m0 + r0 + i * ROWS_PER_PASS;
-            if (m < M) {
-                f32x4 v = tile_v[i] + bv;
+            for (int i = 0; i < E_ROWS; ++i) {
+                f32x4 v = tile_v[i];
                 if (pre_res) v += res[i];
-                if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
-                size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
-                if (p.out_bstride) {
-                    const int b = fast_div(m, P.div_howo);
-                    o = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * cs + p.out_coff + n;
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                *reinterpret_cast<f32x4 *>(op + (size_t)i * step) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E_ROWS; ++i) {
+                const int m = m0 + r0 + i * ROWS_PER_PASS;
+                if (m < M) {
+                    f32x4 v = tile_v[i];
+                    if (pre_res) v += res[i];
+                    if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                    size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
+                    if (p.out_bstride) {
+                        const int b = fast_div(m, P.div_howo);
+                        o = (size_t)b * (size_t)p.out_bstride + (size_t)(m - b * HoWo) * cs + p.out_coff + n;
+                    }
+                    *reinterpret_cast<f32x4 *>(p.out + o) = v;
                 }
-                *reinterpret_cast<f32x4 *>(p.out + o) = v;
             }
         }
     } else {

@@ -11,7 +11,7 @@ from masklab_hip import _lib, ops, packing
 lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 rng = np.random.default_rng(0)
-B, H, W, cin, cout, k = 8, 128, 128, 128, 128, 3
+B, H, W, cin, cout, k = [int(v) for v in os.environ.get("STAMP_SHAPE", "8,128,128,128,128,3").split(",")]
 x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
 dc = ops.DeviceConv(packing.pack_dense(rng.normal(size=(k, k, cin, cout)).astype(np.float32) * 0.05, np.zeros(cout, np.float32)), "cuda")
 for _ in range(3):
@@ -22,7 +22,7 @@ assert raw.ml_debug_read_stamps(buf) == 0
 st = np.array(buf[:], dtype=np.uint64).reshape(8, 64).astype(np.int64)
 names = ["loop top -> loads issued", "loads issued -> MFMA block done", "MFMA done -> (wait) LDS store issued",
          "store -> barrier passed", "barrier -> next loop top"]
-n = 36
+n = max(3, min(36, k * k * ((cin + 31) // 32)))
 print("iteration totals (s_memtime ticks, 100 MHz => x ~24 for shader cycles at 2.4 GHz):")
 d = [st[1, :n] - st[0, :n], st[2, :n] - st[1, :n], st[3, :n] - st[2, :n], st[4, :n] - st[3, :n]]
 tot = st[0, 1:n] - st[0, :n - 1]
