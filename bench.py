@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write one line per profiled launch to this file")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay stage 1 of the forward from a hipGraph (launch-bound small batches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +167,8 @@ def main():
         ops.set_conv_math("f16")       # dense convs: fp16 operands, fp32 accumulate; tensors stay fp32 in HBM
     cfg, model, weights = build_model(backbone, device)
     images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
+    if args.graph:
+        model.enable_graphs(True)
 
     def mark(msg):
         if rehearsal:
@@ -274,7 +278,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 MFMA operands, f32 accumulate, f32 tensors" if f16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "backbone": backbone, "per_gpu_batch": B, "global_batch": B * world,
-                       "height": H, "width": W, "parallelism": f"dp{world}",
+                       "height": H, "width": W, "parallelism": f"dp{world}", "hipgraph": bool(args.graph),
                        "weights": "random init (cls logits x8 so NMS / mask head run at full load)",
                        "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": per_kernel,

@@ -124,6 +124,8 @@ class InferenceModel(K.Layer):
         self.layers = self._flat_layers()
         self.device = None
         self.last_detections = None
+        self._use_graphs = False
+        self._graphs = {}
         self._build_shapes()
 
     # ---- structure
@@ -188,17 +190,15 @@ class InferenceModel(K.Layer):
         return self
 
     # ---- forward (reference :431-491)
-    def call(self, images, **kwargs):
+    # Stage 1 = everything up to the one host read (backbone, FPN, towers, box decode, DetectionProposal,
+    # level assignment, semantic head); stage 2 = RoI crops + mask head, whose molded shapes depend on the
+    # RoI counts the host reads in between (the reference's dynamic shapes).
+    def _stage1(self, images, want_kept=False):
         cfg = self.configuration
-        if not isinstance(images, torch.Tensor):
-            images = torch.as_tensor(np.asarray(images))
-        if self.device is None:
-            raise RuntimeError("InferenceModel: call load_weights(weights, device) first")
-        images = images.to(self.device).contiguous()
         bb = self.backbone_network
         feats = bb(images)
         by_name = dict(zip(bb.output_names, feats))
-        outputs = []
+        st = {"image_hw": (int(images.shape[1]), int(images.shape[2]))}
 
         def semantic_head():
             seg_config = cfg.semantic
@@ -206,7 +206,6 @@ class InferenceModel(K.Layer):
             aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
             return seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]])
 
-        seg_pred = None
         if self.detection_networks is not None:
             det_config = cfg.detection
             prior_subnet, fpn_subnet, cls_subnet, loc_subnet = self.detection_networks
@@ -214,34 +213,86 @@ class InferenceModel(K.Layer):
             fpn_inputs = [by_name[n] for n in bb.output_names if n in det_config.feature_pyramid_inputs]
             without_fpn = [by_name[n] for n in bb.output_names if n not in det_config.feature_pyramid_inputs]
             feature_outputs = fpn_subnet(fpn_inputs) + without_fpn
-            cls_pred = cls_subnet(feature_outputs)
-            loc_pred = loc_subnet(feature_outputs)
-            outputs += [cls_pred, loc_pred]
+            st["cls_pred"] = cls_subnet(feature_outputs)
+            st["loc_pred"] = loc_subnet(feature_outputs)
             if self.instance_networks is not None:
-                restore_subnet, distribute_subnet, pyramid_roi_align, mask_subnet = self.instance_networks
-                restored_boxes = restore_subnet([loc_pred, pr_boxes])
+                restore_subnet, distribute_subnet, pyramid_roi_align, _ = self.instance_networks
+                restored_boxes = restore_subnet([st["loc_pred"], pr_boxes])
                 # fused DetectionProposal -> MaskDistribute -> PyramidRoiAlign in fixed capacity:
                 # the only host read is the per-level RoI count that sizes the molded outputs.
                 proposed, counts, kept = self.detection_proposal.propose_fixed(
-                    cls_pred, restored_boxes, want_kept=kwargs.get("want_kept", False))
+                    st["cls_pred"], restored_boxes, want_kept=want_kept)
                 n_levels = cfg.instance.max_k + 1
                 if distribute_subnet.max_k + 1 != n_levels:
                     raise ValueError("MaskDistribute.max_k does not match config.instance.max_k")
-                image_hw = (int(images.shape[1]), int(images.shape[2]))
                 slots, lcounts = pyramid_roi_align.distribute(n_levels, proposed, has_k=False,
                                                               base_size=distribute_subnet.base_size)
-                if self.semantic_networks is not None:
-                    # independent of the instance branch: enqueue it BEFORE the host reads the RoI counts,
-                    # so the GPU stays busy while the host waits (same stream, same results)
-                    seg_pred = semantic_head()
+                st.update(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes, slots=slots,
+                          lcounts=lcounts, roi_features=feature_outputs[:n_levels])
+        if self.semantic_networks is not None:
+            # independent of the instance branch and enqueued BEFORE the host reads the RoI counts, so the
+            # GPU stays busy while the host waits (same stream, same results)
+            st["seg_pred"] = semantic_head()
+        return st
+
+    def _stage2(self, st):
+        outputs = []
+        if self.detection_networks is not None:
+            outputs += [st["cls_pred"], st["loc_pred"]]
+            if self.instance_networks is not None:
+                _, _, pyramid_roi_align, mask_subnet = self.instance_networks
                 roi_fmaps, roi_boxes = pyramid_roi_align.crop_distributed(
-                    feature_outputs[:n_levels], proposed, image_hw, slots, lcounts)
+                    st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"])
                 roi_masks = mask_subnet(roi_fmaps)
                 outputs += [roi_boxes, roi_masks]
-                self.last_detections = dict(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes)
+                self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"],
+                                            boxes=st["boxes"])
         if self.semantic_networks is not None:
-            outputs.append(seg_pred if seg_pred is not None else semantic_head())
+            outputs.append(st["seg_pred"])
         return outputs
+
+    # ---- hipGraph replay of stage 1 (launch-bound small batches: serving one image at a time)
+    def enable_graphs(self, enabled=True):
+        """Capture stage 1 (~250 kernel launches) into a hipGraph per input shape and replay it: one
+        launch instead of hundreds, which is what a batch-1 forward is bound by.  The tensors stage 1
+        returns (cls_pred, loc_pred, seg_pred) are then graph-owned buffers, valid until the next call."""
+        self._use_graphs = bool(enabled)
+        if not enabled:
+            self._graphs = {}
+        return self
+
+    def _stage1_graphed(self, images):
+        from . import ops
+        key = (tuple(images.shape), images.dtype, ops.CONV_MATH)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if ops.PROFILE is not None:
+                raise RuntimeError("graph capture cannot run under the per-launch profiling hook")
+            self._stage1(images)                     # warm-up: fills the anchor / workspace caches, sets kernel attributes
+            torch.cuda.synchronize(self.device)
+            static_in = images.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st = self._stage1(static_in)
+            entry = self._graphs[key] = (graph, static_in, st)
+        graph, static_in, st = entry
+        static_in.copy_(images)
+        graph.replay()
+        return st
+
+    def call(self, images, **kwargs):
+        if not isinstance(images, torch.Tensor):
+            images = torch.as_tensor(np.asarray(images))
+        if self.device is None:
+            raise RuntimeError("InferenceModel: call load_weights(weights, device) first")
+        images = images.to(self.device).contiguous()
+        want_kept = kwargs.get("want_kept", False)
+        from . import ops
+        if getattr(self, "_use_graphs", False) and not want_kept and ops.PROFILE is None:
+            st = self._stage1_graphed(images)
+        else:
+            st = self._stage1(images, want_kept=want_kept)
+        return self._stage2(st)
 
     def predict(self, images, **kwargs):
         """Keras `Model.predict`: numpy in, list of numpy out."""

@@ -175,3 +175,28 @@ def test_full_forward_with_squeeze_excite_and_separable_conv():
     cfg.semantic.use_separable_conv = True
     with pytest.raises(ValueError):
         R.construct_masklab_networks(cfg)
+
+
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50"])
+def test_hipgraph_replay_equals_eager(bt):
+    """enable_graphs(): stage 1 captured into a hipGraph and replayed gives bit-identical outputs to the eager
+    launches (same kernels, same order), for the image it was captured on and for a different one."""
+    cfg, model, w = _build(bt, seed=5, hot_cls=True)
+    rng = np.random.default_rng(7)
+    imgs = [rng.integers(0, 256, (1, 128, 256, 3), dtype=np.uint8) for _ in range(3)]
+    eager = [model.predict(im) for im in imgs]
+    model.enable_graphs(True)
+    for rep in range(2):                                   # first pass captures, second only replays
+        for im, want in zip(imgs, eager):
+            got = model.predict(im)
+            for name, g, r in zip(model.output_names, got, want):
+                np.testing.assert_array_equal(g, r, err_msg=f"{name} (pass {rep})")
+    assert len(model._graphs) == 1
+    other = rng.integers(0, 256, (2, 128, 128, 3), dtype=np.uint8)     # a second shape gets its own graph
+    model.enable_graphs(False)
+    want = model.predict(other)
+    model.enable_graphs(True)
+    got = model.predict(other)
+    for g, r in zip(got, want):
+        np.testing.assert_array_equal(g, r)
+    model.enable_graphs(False)
