@@ -45,10 +45,14 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
     const long long hi = min(lo + slice, L);
     double sum = 0.0, sq = 0.0;
     if (VEC4) {
+        // a float4 is folded in fp32 first (3 adds, 4 fma), then joins the fp64 running sums: the kernel was
+        // bound by its fp64 instruction count (12 per float4), not by HBM
         for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = v[e]; sum += d; sq += d * d; }
+            const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+            const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+            sum += (double)s4;
+            sq += (double)q4;
         }
     } else {
         for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) { const double d = p[i]; sum += d; sq += d * d; }
@@ -99,7 +103,37 @@ __global__ void gn_apply_kernel(const float *x, float *y, const float *__restric
     const long long hi = min(lo + slice, L);
     // flat index inside the sample = g*L + i ; channel = that mod C
     const long long gbase = (long long)g * L;
-    if (VEC4) {
+    if (VEC4 && (cg % 4 == 0) && HWC < (1ll << 31)) {
+        // Hot form: a float4 never straddles a gamma period (cg % 4 == 0) and the flat index fits 32 bits, so
+        // channel / pixel / gamma offset advance incrementally -- no division or modulo inside the loop (the
+        // 64-bit `%` and `/` per float4 made this pass VALU-bound)
+        const unsigned Cu = (unsigned)C, cgu = (unsigned)cg;
+        const long long i0 = lo + threadIdx.x * 4;
+        const unsigned f0 = (unsigned)(gbase + i0);
+        unsigned c0 = f0 % Cu, pix = f0 / Cu, cm = c0 % cgu;
+        const unsigned stepc = (GN_TPB * 4u) % Cu, steppix = (GN_TPB * 4u) / Cu, stepm = (GN_TPB * 4u) % cgu;
+        const float *gp = gamma ? gamma + g * cg : nullptr;
+        const float *bp = beta ? beta + g * cg : nullptr;
+        for (long long i = i0; i < hi; i += GN_TPB * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd;
+            if (gp) o *= *reinterpret_cast<const f32x4 *>(gp + cm);
+            if (bp) o += *reinterpret_cast<const f32x4 *>(bp + cm);
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
+            else *reinterpret_cast<f32x4 *>(q + (long long)pix * out_cs + c0) = o;
+            c0 += stepc;
+            pix += steppix;
+            if (c0 >= Cu) { c0 -= Cu; ++pix; }
+            cm += stepm;
+            if (cm >= cgu) cm -= cgu;
+        }
+    } else if (VEC4) {
         for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
             const int c0 = (int)((gbase + i) % C);
