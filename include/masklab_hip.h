@@ -84,7 +84,7 @@ int ml_conv2d_f32(const ml_conv2d_desc *d, void *stream);
 
 /* Several independent conv problems of the SAME tile shape in one launch (the un-shared head
  * towers run the same conv at every pyramid level: detection.py:109-130,179-202, instance.py:177-201).
- * With n == 1 and a workspace, a problem with few output tiles and a long K is split along K
+ * With a workspace, a launch with few output tiles in total and a long K is split along K
  * (partials in the workspace, fixed-order reduction: deterministic).  workspace may be NULL.   */
 #define ML_CONV_MAX_PROBLEMS 12
 int64_t ml_conv2d_workspace_bytes(void);

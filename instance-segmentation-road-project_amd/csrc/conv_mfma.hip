@@ -561,11 +561,25 @@ conv_mfma_kernel(const MultiArgs args) {
 #endif
 }
 
-// out = act(sum_s slab[s] + bias + residual), slices summed in index order (deterministic)
+// out = act(sum_s slab[s] + bias + residual), slices summed in index order (deterministic).
+// One launch reduces every split problem of a multi-problem conv launch.
+struct ReduceArgs {
+    int n;
+    int start[MAXP + 1];      // prefix sum of reduce blocks per problem
+    int m_pad[MAXP];
+    Problem p[MAXP];
+};
+
 __global__ void __launch_bounds__(256)
-splitk_reduce_kernel(const ml_conv2d_desc p, const float *__restrict__ slab, int splits, int M, int m_pad) {
+splitk_reduce_kernel(const ReduceArgs args) {
+    int pi = 0;
+    while (pi + 1 < args.n && (int)blockIdx.x >= args.start[pi + 1]) ++pi;
+    const Problem &P = args.p[pi];
+    const ml_conv2d_desc &p = P.d;
+    const float *__restrict__ slab = P.slab;
+    const int splits = P.splits, M = P.M, m_pad = args.m_pad[pi];
     const int V = p.n_pad / 4;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)(blockIdx.x - args.start[pi]) * 256 + threadIdx.x;
     if (idx >= (long long)M * V) return;
     const int m = (int)(idx / V);
     const int n = (int)(idx % V) * 4;
@@ -659,6 +673,13 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     MultiArgs args;
     args.n = n;
     long long start = 0, ws_off = 0;
+    // split-K looks at the whole launch: five pyramid levels of one image are 171 tiles together -- a third of
+    // the chip -- and each tile then walks all 36 chunks alone (92 us); slicing K fills the other CUs
+    long long launch_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
+        launch_tiles += ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
+    }
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
         Problem &P = args.p[i];
@@ -675,7 +696,7 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * 4);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
-        int splits = (n == 1 && workspace) ? choose_splits((long long)P.MB * P.NB, chunks) : 1;
+        int splits = workspace ? choose_splits(launch_tiles, chunks) : 1;
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
         if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
         P.cps = (chunks + splits - 1) / splits;
@@ -694,14 +715,24 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     args.start[n] = (int)start;
     hipLaunchKernelGGL(kern, dim3((unsigned)start), dim3(256), LDS_BYTES, s, args);
     ML_CHECK_LAUNCH("conv2d");
+    ReduceArgs ra;
+    ra.n = 0;
+    long long rblocks = 0;
     for (int i = 0; i < n; ++i) {
         const Problem &P = args.p[i];
         if (P.splits > 1) {
             const long long work = (long long)P.M * (P.d.n_pad / 4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, P.d, P.slab,
-                               P.splits, P.M, P.MB * BM);
-            ML_CHECK_LAUNCH("conv2d split-K reduce");
+            ra.p[ra.n] = P;
+            ra.m_pad[ra.n] = P.MB * BM;
+            ra.start[ra.n] = (int)rblocks;
+            rblocks += (work + 255) / 256;
+            ++ra.n;
         }
+    }
+    if (ra.n > 0) {
+        ra.start[ra.n] = (int)rblocks;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, ra);
+        ML_CHECK_LAUNCH("conv2d split-K reduce");
     }
     return ML_OK;
 }

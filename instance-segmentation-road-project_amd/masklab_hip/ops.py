@@ -187,8 +187,9 @@ def conv2d_multi(problems):
         flops += f
         nbytes += nb
     name = _conv_kernel_name(problems[0]["dc"].p)
+    ws = workspace(int(lib.ml_conv2d_workspace_bytes()), problems[0]["x"].device, "conv")
     with _Prof(name, flops, nbytes, f"multi x{n}"):
-        _lib.check(lib.ml_conv2d_multi_f32(arr, n, None, 0, _stream()), "ml_conv2d_multi_f32")
+        _lib.check(lib.ml_conv2d_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return rets
 
 
