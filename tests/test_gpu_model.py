@@ -200,3 +200,34 @@ def test_hipgraph_replay_equals_eager(bt):
     for g, r in zip(got, want):
         np.testing.assert_array_equal(g, r)
     model.enable_graphs(False)
+
+
+@pytest.mark.parametrize("bt,shape", [
+    ("resnext50", (3, 192, 320, 3)),        # non-square, level sizes 24x40 .. 2x3 (odd at P6/P7)
+    ("resnext50", (1, 136, 200, 3)),        # not a multiple of the strides: 'same' ceil sizes 17x25, 9x13, 5x7, 3x4, 2x2
+    ("mobilenet", (5, 128, 384, 3)),        # odd batch
+    ("mobilenet", (32, 128, 128, 3)),       # the MoldBatch maximum (reference misc.py:275)
+])
+def test_full_forward_other_shapes(bt, shape):
+    cfg, model, w = _build(bt, seed=11, hot_cls=True)
+    images = np.random.default_rng(shape[0] * 7 + shape[2]).integers(0, 256, shape, dtype=np.uint8)
+    # thresholding is discontinuous: put min_confidence in the widest score gap near 0.6 (see above)
+    cls_ref = O.inference_forward(cfg, w, images, literal_groups=False, with_instance=False, with_semantic=False)[0]
+    sc = np.sort(cls_ref[(cls_ref > 0.55) & (cls_ref < 0.65)].astype(np.float64))
+    gaps = np.diff(sc)
+    i = int(np.argmax(gaps))
+    assert gaps[i] > 2e-5, "no usable gap in the score distribution"      # GPU-vs-oracle score differences are ~1e-6
+    thr = float(np.float32((sc[i] + sc[i + 1]) / 2))
+    cfg.detection.min_confidence = thr
+    model.detection_proposal.min_confidence = thr
+    got = model.predict(images)
+    want = O.inference_forward(cfg, w, images, literal_groups=False)
+    assert (want[2][..., 4] >= 0).sum() > 0, "fixture produced no detections"
+    _check(model, got, want)
+
+
+def test_more_than_32_images_is_refused_like_the_reference():
+    cfg, model, w = _build("mobilenet", seed=1)
+    images = np.zeros((33, 128, 128, 3), np.uint8)
+    with pytest.raises(ValueError, match="32"):
+        model.predict(images)
