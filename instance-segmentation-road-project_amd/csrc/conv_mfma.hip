@@ -43,7 +43,9 @@ extern "C" int ml_debug_read_stamps(unsigned long long *host) {
 
 namespace {
 
-constexpr int LDS_LD = 36;   // floats per staged row (32 + 4 pad)
+constexpr int LDS_LD = 32;   // f32 math: floats per staged row.  No padding: rows are filled by LDS-direct loads
+                             // (64 lanes x 16 B land contiguously); bank conflicts are avoided by an XOR swizzle
+                             // of the 16-byte k-groups inside a row: slot = kgroup ^ ((row >> 1) & 7)
 constexpr int LDS_LD_H = 40; // f16 math: halves per staged row (32 + 8 pad: 80-byte rows, conflict-free b128 reads)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -86,6 +88,15 @@ struct MultiArgs {
     int start[MAXP + 1];      // prefix sum of blocks per problem
     Problem p[MAXP];
 };
+
+// buffer_load_dwordx4 ... lds: 16 bytes per lane from (resource + voff + soff) straight into LDS at
+// dst + lane * 16 (dst is wave-uniform and travels in M0); out-of-range lanes write zeros.  Counted in vmcnt.
+// (The builtin only exists in the device pass.)
+__device__ __forceinline__ void load_b128_to_lds(__amdgpu_buffer_rsrc_t rsrc, float *dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)dst, 16, voff, soff, 0, 0);
+#endif
+}
 
 // ---- shared epilogue math: bias + residual + activation + addressing for 4 consecutive channels
 __device__ __forceinline__ void store_out4(const ml_conv2d_desc &p, int HoWo, int m, int n, f32x4 v, bool vec_ok,
@@ -149,7 +160,7 @@ conv_mfma_kernel(const MultiArgs args) {
     constexpr int B_LD = BN / 32;
     constexpr int BUF = F16 ? (BM + BN) * LDS_LD_H / 2 : (BM + BN) * LDS_LD;    // floats per staging buffer
     constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
-    static_assert(F16 || BM * C_LD <= 2 * BUF, "epilogue tile must fit in the staging buffers");
+    // (the launcher sizes the dynamic LDS as max(two staging buffers, epilogue tile))
     extern __shared__ __align__(16) float lds[];
     STAMP1(0);
 
@@ -178,7 +189,9 @@ conv_mfma_kernel(const MultiArgs args) {
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
     const int ld_row = tid >> 3;
-    const int ld_c = (tid & 7) * 4;
+    // f32 math: lane (row, slot) of a staging load FETCHES k-group slot ^ ((row >> 1) & 7), so the linear LDS
+    // image the load writes is the swizzled one (row + 32 i has the same swizzle key)
+    const int ld_c = F16 ? (tid & 7) * 4 : (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4);
 
     // ---- per-thread pixel coordinates of the A rows it stages.  a_voff[i] = byte offset of the
     // row's tap-(0,0) pixel, channel gofs + ld_c: per chunk only a wave-uniform (tap, channel) offset
@@ -270,6 +283,8 @@ conv_mfma_kernel(const MultiArgs args) {
     // the 64-cycle shadow of the wave's OWN MFMAs.  All pieces are branch-free (selects / masks only).
     int nx_px = 0;
     bool nx_cok = true;
+    int dst_buf = 0;                                      // staging buffer the pieces fill
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto piece_begin = [&]() {
         const int c = cc * 32 + ld_c;
         nx_px = c >> pshift;                     // 0 unless a tap spans pixels (NHWC4 stems)
@@ -290,10 +305,19 @@ conv_mfma_kernel(const MultiArgs args) {
             const bool ok = ((unsigned)iy < (unsigned)pH) && ((unsigned)(ix + nx_px) < (unsigned)pW) && nx_cok;
             vo = ok ? vo : (int)0x80000000;      // out of range => hardware returns zeros
         }
-        areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
+        if constexpr (F16) {
+            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
+        } else {
+            // global -> LDS without a register round trip: this wave's 64 x 16 B = rows 32i + 8w .. +7 of the tile
+            load_b128_to_lds(rsrc_a, lds + dst_buf * BUF + (32 * i + 8 * wave_u) * LDS_LD, vo, 0);
+        }
     };
     auto piece_b = [&](int i, int kc) {
-        breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], kc * 128, 0));
+        if constexpr (F16) {
+            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], kc * 128, 0));
+        } else {
+            load_b128_to_lds(rsrc_b, lds + dst_buf * BUF + (BM + 32 * i + 8 * wave_u) * LDS_LD, b_voff[i], kc * 128);
+        }
     };
     auto piece_end = [&]() {                     // advance (kh, kw, cc) and the running offsets with selects
         const bool wrap_c = (cc + 1 == ncpt);
@@ -329,14 +353,8 @@ conv_mfma_kernel(const MultiArgs args) {
             }
             return;
         }
-        float *As = lds + buf * BUF;
-        float *Bs = As + BM * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<f32x4 *>(As + (ld_row + 32 * i) * LDS_LD + ld_c) = areg[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<f32x4 *>(Bs + (ld_row + 32 * i) * LDS_LD + ld_c) = breg[i];
+        // f32 math: the data is already on its way into LDS; it has landed when vmcnt reaches 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     const int r = lane & 31;
@@ -356,9 +374,9 @@ conv_mfma_kernel(const MultiArgs args) {
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b0;
     }
 
-    const int a_off = F16 ? (wm * TM * 32 + r) * LDS_LD_H + h * 8 : (wm * TM * 32 + r) * LDS_LD + h * 4;
-    const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8
-                          : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
+    const int a_off = F16 ? (wm * TM * 32 + r) * LDS_LD_H + h * 8 : (wm * TM * 32 + r) * LDS_LD;
+    const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8 : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD;
+    const int swz = (r >> 1) & 7;                         // f32 math: k-group kg of row r sits in slot kg ^ swz
 
     STAMP1(1);
     if (kc_begin < kc_end) {
@@ -382,6 +400,7 @@ conv_mfma_kernel(const MultiArgs args) {
         const int kc_next = more ? kc + 1 : kc;
         STAMP(1);
         const float *base = lds + buf * BUF;
+        dst_buf = buf ^ 1;
         piece_begin();
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NPIECE = A_LD + B_LD + 1;              // + piece_end
@@ -428,10 +447,10 @@ conv_mfma_kernel(const MultiArgs args) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
-                a[mi] = *reinterpret_cast<const f32x4 *>(base + a_off + mi * 32 * LDS_LD + ks * 8);
+                a[mi] = *reinterpret_cast<const f32x4 *>(base + a_off + mi * 32 * LDS_LD + (((ks * 2 + h) ^ swz) * 4));
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                b[ni] = *reinterpret_cast<const f32x4 *>(base + b_off + ni * 32 * LDS_LD + ks * 8);
+                b[ni] = *reinterpret_cast<const f32x4 *>(base + b_off + ni * 32 * LDS_LD + (((ks * 2 + h) ^ swz) * 4));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -455,7 +474,11 @@ conv_mfma_kernel(const MultiArgs args) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(5);
 #endif
-        if (more) store_chunk(buf ^ 1);
+        if constexpr (F16) {
+            if (more) store_chunk(buf ^ 1);
+        } else {
+            store_chunk(buf ^ 1);        // always: the (dropped) last prefetch must have landed before the epilogue re-uses the LDS
+        }
         STAMP(3);
         __syncthreads();
         STAMP(4);
