@@ -231,6 +231,37 @@ int ml_threshold_i32(const float *in, int32_t *out, float threshold, int64_t n, 
 int ml_semantic_smoothing_f32(const float *in, float *out, float *tmp, int32_t B, int32_t H, int32_t W, int32_t C,
                               const int32_t *kernel_sizes, const float *weights, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Serving post-processing (reference road_project/setup/serving.py:28-50) -- SURVEY section 8(f) rank 4.
+ * Only the arithmetic layers: JPEG decode / drawing / encode are outside this library.
+ * ------------------------------------------------------------------------------------------- */
+
+/* CropAndPadMask.call (engine/layers/misc.py:358-401): det [B,n,6] int32 (cx,cy,w,h,label,conf*100 from
+ * UpSampleOutput), masks [B,n,mh,mw] int32 -> out [B,n,H,W] f32: for every row with conf >= threshold
+ * (threshold = 50 if max(conf) > 50 else -100) the mask resized bilinear(align_corners=True) to its box
+ * (box = max(box, 1); corners ceil(c -+ size/2) clipped to the canvas) and zero padded to H x W; other
+ * rows zero.  A box clipped to zero size pastes nothing (the reference's resize would raise).
+ * threshold_ws: one int32 of device scratch.                                                       */
+int ml_crop_pad_mask_f32(const int32_t *det, const int32_t *masks, float *out, int32_t *threshold_ws,
+                         int32_t B, int32_t n, int32_t mh, int32_t mw, int32_t H, int32_t W, void *stream);
+
+/* CrackToInstance.call bounding box (engine/layers/misc.py:533-541): min / max (y, x) of the non-zero
+ * entries of channel `coff` of an int32 [B,H,W,cstride] map over the WHOLE batch.  box5 (device, caller
+ * initialises to {INT32_MAX, INT32_MAX, -1, -1, 0}) receives {ymin, xmin, ymax, xmax, any}.           */
+int ml_nonzero_bbox_i32(const int32_t *map, int32_t B, int32_t H, int32_t W, int32_t cstride, int32_t coff,
+                        int32_t *box5, void *stream);
+
+/* SummaryOutput's per-instance numbers (engine/layers/misc.py:574-589): CalculateInstanceSize (:632-718:
+ * per image row the min / max x of the `road_channel` pixels > 0, rows with min != max, 15 % dropped at
+ * both ends, least-squares lines x(y) of the left and right edge -- float32 normal equations, 2x2 LU with
+ * partial pivoting like tf.linalg.inv --, unit[y] = default_road_size / clip(right - left, 1, inf)) and
+ * IncludeMyRoad (:601-618).  seg [B,H,W,seg_channels] int32, masks [B,n,H,W] f32 (CropAndPadMask output)
+ * -> out5 [B,n,5] = {pixel sum, instance size, horizontal size, vertical size, include_my_road}.     */
+int64_t ml_instance_summary_workspace_bytes(int32_t B, int32_t H);
+int ml_instance_summary_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const float *masks,
+                            float *out5, int32_t B, int32_t n, int32_t H, int32_t W, float default_road_size,
+                            float ioi_threshold, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,3 +225,314 @@ extern "C" int ml_semantic_smoothing_f32(const float *in, float *out, float *tmp
     ML_CHECK_LAUNCH("semantic_smoothing");
     return ML_OK;
 }
+
+// =====================================================================================================
+// Serving post-processing (reference engine/layers/misc.py:358-401, 554-718,
+// assembled in road_project/setup/serving.py:28-50): CropAndPadMask, CrackToInstance, CalculateInstanceSize,
+// IncludeMyRoad -- the numeric half of the serving graph (JPEG decode / drawing / encode are not arithmetic
+// on this path and stay outside).  All of it is byte / element streaming plus small reductions.
+// =====================================================================================================
+namespace {
+
+// ---- CropAndPadMask: threshold = max(conf) > 50 ? 50 : -100 (misc.py:371-374), one block
+__global__ void __launch_bounds__(256) conf_threshold_kernel(const int32_t *__restrict__ det, int rows, int32_t *thr) {
+    __shared__ int red[256];
+    int m = INT32_MIN;
+    for (int i = threadIdx.x; i < rows; i += 256) m = max(m, det[i * 6 + 5]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *thr = red[0] > 50 ? 50 : -100;
+}
+
+// out[b,i,y,x]: the mh x mw mask of a selected instance resized (bilinear, align_corners) to its box and
+// placed at (ymin, xmin) of an H x W canvas of zeros (misc.py:377-398).  One thread per canvas pixel.
+__global__ void crop_pad_mask_kernel(const int32_t *__restrict__ det, const int32_t *__restrict__ masks,
+                                     const int32_t *__restrict__ thr, float *__restrict__ out, int n, int mh, int mw,
+                                     int H, int W, long long total) {
+    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    long long t = idx / W;
+    const int y = (int)(t % H);
+    const long long row = t / H;                 // b * n + i
+    const int32_t *d = det + row * 6;
+    float v = 0.f;
+    if (d[5] >= *thr) {
+        // box = max(box, 1) elementwise, then float (misc.py:378-382)
+        const float cx = (float)max(d[0], 1), cy = (float)max(d[1], 1), w = (float)max(d[2], 1), h = (float)max(d[3], 1);
+        const int xmin = min(max((int)ceilf(cx - w / 2.f), 0), W), xmax = min(max((int)ceilf(cx + w / 2.f), 0), W);
+        const int ymin = min(max((int)ceilf(cy - h / 2.f), 0), H), ymax = min(max((int)ceilf(cy + h / 2.f), 0), H);
+        const int oh = ymax - ymin, ow = xmax - xmin;
+        if (y >= ymin && y < ymax && x >= xmin && x < xmax) {      // (a zero-sized box pastes nothing)
+            const float sy = oh > 1 ? (float)(mh - 1) / (float)(oh - 1) : 0.f;
+            const float sx = ow > 1 ? (float)(mw - 1) / (float)(ow - 1) : 0.f;
+            const float fy = (float)(y - ymin) * sy, fx = (float)(x - xmin) * sx;
+            const float fly = floorf(fy), flx = floorf(fx);
+            const int y0 = max((int)fly, 0), x0 = max((int)flx, 0);
+            const int y1 = min((int)ceilf(fy), mh - 1), x1 = min((int)ceilf(fx), mw - 1);
+            const float ty = fy - fly, tx = fx - flx;
+            const int32_t *m = masks + row * mh * mw;
+            const float tl = (float)m[y0 * mw + x0], tr = (float)m[y0 * mw + x1];
+            const float bl = (float)m[y1 * mw + x0], br = (float)m[y1 * mw + x1];
+            const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+            v = top + (bot - top) * ty;
+        }
+    }
+    out[idx] = v;
+}
+
+// ---- CrackToInstance (misc.py:524-551): bounding box of the non-zero pixels of a [B,H,W] int32 map over the
+// WHOLE batch (the reference reduces tf.where over all rows).  box = {ymin, xmin, ymax, xmax, any}
+__global__ void nonzero_bbox_kernel(const int32_t *__restrict__ map, int cstride, int coff, int H, int W, long long total,
+                                    int32_t *__restrict__ box) {
+    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    if (map[idx * cstride + coff] != 0) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        atomicMin(&box[0], y);
+        atomicMin(&box[1], x);
+        atomicMax(&box[2], y);
+        atomicMax(&box[3], x);
+        box[4] = 1;
+    }
+}
+
+// ---- CalculateInstanceSize (misc.py:632-718)
+// per image row: min / max x of the road pixels (tf.segment_min / segment_max over tf.where, :683-684);
+// rows without road pixels read 0 / 0 like an empty TF segment.  grid (H, B), block 64.
+__global__ void __launch_bounds__(64) road_row_extent_kernel(const int32_t *__restrict__ seg, int cstride, int coff, int H,
+                                                             int W, int32_t *__restrict__ xmin, int32_t *__restrict__ xmax,
+                                                             int32_t *__restrict__ last_row) {
+    const int y = blockIdx.x, b = blockIdx.y;
+    const int32_t *row = seg + ((long long)(b * H + y) * W) * cstride + coff;
+    int lo = INT32_MAX, hi = -1;
+    for (int x = threadIdx.x; x < W; x += 64)
+        if (row[(long long)x * cstride] > 0) { lo = min(lo, x); hi = max(hi, x); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off, 64));
+        hi = max(hi, __shfl_down(hi, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        xmin[b * H + y] = hi >= 0 ? lo : 0;
+        xmax[b * H + y] = hi >= 0 ? hi : 0;
+        if (hi >= 0) atomicMax(&last_row[b], y);          // segment ids run 0 .. max(y) (:683-685)
+    }
+}
+
+// 2x2 inverse through LU with partial pivoting in float32 (what Eigen / LAPACK do for tf.linalg.inv / det)
+__device__ void theta_from_sums(double syy, double sy, double cnt, double syx, double sx, float *theta) {
+    const float a = (float)syy, b = (float)sy, c = (float)sy, d = (float)cnt;     // X^T X = [[a b] [c d]]
+    const float r0 = (float)syx, r1 = (float)sx;                                  // X^T y
+    theta[0] = theta[1] = 0.f;
+    // LU, pivot on the larger of |a|, |c|
+    float p00, p01, p10, p11, q0, q1;
+    float sign = 1.f;
+    if (fabsf(c) > fabsf(a)) { p00 = c; p01 = d; p10 = a; p11 = b; q0 = r1; q1 = r0; sign = -1.f; }
+    else { p00 = a; p01 = b; p10 = c; p11 = d; q0 = r0; q1 = r1; }
+    if (p00 == 0.f) return;
+    const float l = p10 / p00;
+    const float u11 = p11 - l * p01;
+    const float det = sign * p00 * u11;
+    if (!(det > 0.f)) return;                                                     // tf.cond(det_x > 0, ..., zeros) (:708-711)
+    const float z1 = q1 - l * q0;
+    const float t1 = z1 / u11;
+    const float t0 = (q0 - p01 * t1) / p00;
+    theta[0] = t0;
+    theta[1] = t1;
+}
+
+// one block per image: marginal points (rows with x_min != x_max), 15 % dropped at both ends, least squares of
+// x on y for the left and the right edge, unit[b,y] = default_road_size / clip(right(y) - left(y), 1, inf)
+__global__ void __launch_bounds__(256) road_unit_length_kernel(const int32_t *__restrict__ xmin, const int32_t *__restrict__ xmax,
+                                                               const int32_t *__restrict__ last_row, int H,
+                                                               float default_road_size, float *__restrict__ unit) {
+    __shared__ int wtot[4], s_valid;
+    __shared__ double red[6][4];
+    __shared__ float th[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = last_row[b] + 1;            // 0 when the image has no road pixel
+    const int32_t *lo = xmin + b * H, *hi = xmax + b * H;
+    // pass 1: number of valid rows
+    int cnt = 0;
+    for (int y = tid; y < rows; y += 256) cnt += lo[y] != hi[y];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) wtot[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) s_valid = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    const int valid = s_valid;
+    int drop = (int)((float)valid * 0.15f);      // tf.cast(valid_counts * 0.15, int32), clipped to >= 1 (:695-697)
+    if (drop < 1) drop = 1;
+    // pass 2: ordered rank of every valid row, sums over ranks [drop, valid - drop)
+    double syy = 0, sy = 0, n = 0, sxl = 0, syxl = 0, sxr = 0, syxr = 0;
+    int base = 0;
+    for (int y0 = 0; y0 < rows; y0 += 256) {
+        const int y = y0 + tid;
+        const bool v = y < rows && lo[y] != hi[y];
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        const int rank = before + __popcll(m & ((1ull << lane) - 1));
+        if (v && rank >= drop && rank < valid - drop) {
+            const double yy = (double)y;
+            syy += yy * yy; sy += yy; n += 1.0;
+            sxl += (double)lo[y]; syxl += yy * (double)lo[y];
+            sxr += (double)hi[y]; syxr += yy * (double)hi[y];
+        }
+        base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    double vals[7] = {syy, sy, n, sxl, syxl, sxr, syxr};
+    double tot[7];
+    for (int k = 0; k < 7; ++k) {
+        double v = vals[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k % 6][wave] = v;
+        __syncthreads();
+        tot[k] = red[k % 6][0] + red[k % 6][1] + red[k % 6][2] + red[k % 6][3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        theta_from_sums(tot[0], tot[1], tot[2], tot[4], tot[3], th);          // left edge
+        theta_from_sums(tot[0], tot[1], tot[2], tot[6], tot[5], th + 2);      // right edge
+    }
+    __syncthreads();
+    for (int y = tid; y < H; y += 256) {
+        const float fy = (float)y;
+        const float left = fy * th[0] + th[1], right = fy * th[2] + th[3];
+        const float wdt = fmaxf(right - left, 1.f);
+        unit[b * H + y] = default_road_size / wdt;
+    }
+}
+
+// per (instance, image): rows are dealt to the 4 waves, lanes sweep x.  out5 = {pixel sum, instance size,
+// (horizontal: second kernel), vertical size, include_my_road}
+__global__ void __launch_bounds__(256) instance_rows_kernel(const float *__restrict__ masks, const int32_t *__restrict__ seg,
+                                                            int cstride, int road_coff, const float *__restrict__ unit, int n,
+                                                            int H, int W, float ioi_threshold, float *__restrict__ out5) {
+    __shared__ double red[5][4];
+    const int i = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *m = masks + ((long long)(b * n + i) * H) * W;
+    const int32_t *road = seg + ((long long)b * H * W) * cstride + road_coff;
+    double pix = 0, size = 0, vert = 0, inter = 0, area = 0;
+    for (int y = wave; y < H; y += 4) {
+        const float u = unit[b * H + y];
+        float rs = 0.f;
+        int rin = 0, rar = 0;
+        bool any = false;
+        for (int x = lane; x < W; x += 64) {
+            const float v = m[(long long)y * W + x];
+            rs += v;
+            const bool on = v > 0.5f;
+            any |= on;
+            rar += on;
+            rin += on && (float)road[((long long)y * W + x) * cstride] > 0.5f;
+        }
+        pix += rs;
+        size += (double)(u * u) * rs;
+        if (__ballot(any) != 0 && lane == 0) vert += u;
+        inter += rin;
+        area += rar;
+    }
+    double vals[5] = {pix, size, vert, inter, area};
+    for (int k = 0; k < 5; ++k) {
+        double v = vals[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5];
+        for (int k = 0; k < 5; ++k) t[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+        float *o = out5 + (long long)(b * n + i) * 5;
+        o[0] = (float)t[0];
+        o[1] = (float)t[1];
+        o[3] = (float)t[2];
+        const float ioi = (float)t[3] / ((float)t[4] + 1e-5f);                  // misc.py:617
+        o[4] = ioi > ioi_threshold ? 1.f : 0.f;
+    }
+}
+
+// horizontal size = max over x of sum_y unit[y] * mask[y, x] (misc.py:656-658): threads own columns
+__global__ void __launch_bounds__(256) instance_cols_kernel(const float *__restrict__ masks, const float *__restrict__ unit,
+                                                            int n, int H, int W, float *__restrict__ out5) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, b = blockIdx.y;
+    const float *m = masks + ((long long)(b * n + i) * H) * W;
+    float best = -INFINITY;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        float s = 0.f;
+        for (int y = 0; y < H; ++y) s += unit[b * H + y] * m[(long long)y * W + x];
+        best = fmaxf(best, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out5[(long long)(b * n + i) * 5 + 2] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+}  // namespace
+
+extern "C" int ml_crop_pad_mask_f32(const int32_t *det, const int32_t *masks, float *out, int32_t *threshold_ws, int32_t B,
+                                    int32_t n, int32_t mh, int32_t mw, int32_t H, int32_t W, void *stream) {
+    ML_REQUIRE(det && masks && out && threshold_ws, "crop_pad_mask: null pointer");
+    ML_REQUIRE(B > 0 && n > 0 && mh > 0 && mw > 0 && H > 0 && W > 0, "crop_pad_mask: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conf_threshold_kernel, dim3(1), dim3(256), 0, s, det, B * n, threshold_ws);
+    const long long total = (long long)B * n * H * W;
+    ML_REQUIRE(total / TPB < (1ll << 31), "crop_pad_mask: output too large for one launch");
+    hipLaunchKernelGGL(crop_pad_mask_kernel, dim3(grid_for(total)), dim3(TPB), 0, s, det, masks, threshold_ws, out, n, mh, mw,
+                       H, W, total);
+    ML_CHECK_LAUNCH("crop_pad_mask");
+    return ML_OK;
+}
+
+extern "C" int ml_nonzero_bbox_i32(const int32_t *map, int32_t B, int32_t H, int32_t W, int32_t cstride, int32_t coff,
+                                   int32_t *box5, void *stream) {
+    ML_REQUIRE(map && box5 && B > 0 && H > 0 && W > 0 && cstride > 0 && coff >= 0 && coff < cstride, "nonzero_bbox: bad arguments");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(nonzero_bbox_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, map, cstride, coff, H, W,
+                       total, box5);
+    ML_CHECK_LAUNCH("nonzero_bbox");
+    return ML_OK;
+}
+
+extern "C" int64_t ml_instance_summary_workspace_bytes(int32_t B, int32_t H) {
+    return ((int64_t)B * H * 2 + B) * (int64_t)sizeof(int32_t) + (int64_t)B * H * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int ml_instance_summary_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const float *masks,
+                                       float *out5, int32_t B, int32_t n, int32_t H, int32_t W, float default_road_size,
+                                       float ioi_threshold, void *workspace, void *stream) {
+    ML_REQUIRE(seg && masks && out5 && workspace, "instance_summary: null pointer");
+    ML_REQUIRE(B > 0 && B < 65536 && n > 0 && H > 0 && H < 65536 && W > 0, "instance_summary: bad dims");
+    ML_REQUIRE(road_channel >= 0 && road_channel < seg_channels, "instance_summary: road channel out of range");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *xmin = reinterpret_cast<int32_t *>(workspace);
+    int32_t *xmax = xmin + (size_t)B * H;
+    int32_t *last_row = xmax + (size_t)B * H;
+    float *unit = reinterpret_cast<float *>(last_row + B + ((B & 1) ? 1 : 0));
+    ML_REQUIRE(hipMemsetAsync(last_row, 0xff, (size_t)B * sizeof(int32_t), s) == hipSuccess, "instance_summary: memset failed");
+    hipLaunchKernelGGL(road_row_extent_kernel, dim3(H, B), dim3(64), 0, s, seg, seg_channels, road_channel, H, W, xmin, xmax,
+                       last_row);
+    hipLaunchKernelGGL(road_unit_length_kernel, dim3(B), dim3(256), 0, s, xmin, xmax, last_row, H, default_road_size, unit);
+    hipLaunchKernelGGL(instance_rows_kernel, dim3(n, B), dim3(256), 0, s, masks, seg, seg_channels, road_channel, unit, n, H, W,
+                       ioi_threshold, out5);
+    hipLaunchKernelGGL(instance_cols_kernel, dim3(n, B), dim3(256), 0, s, masks, unit, n, H, W, out5);
+    ML_CHECK_LAUNCH("instance_summary");
+    return ML_OK;
+}

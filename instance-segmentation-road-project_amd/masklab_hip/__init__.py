@@ -18,7 +18,8 @@ def get_custom_objects():
              "BoxRegressionSubNet", "MaskSubNet", "NormalizeBoxes", "DetectionProposal", "MoldBatch",
              "MaskDistribute", "PyramidRoiAlign", "ResizeLike", "AtrousSeparableConv2D", "ASPPNetwork",
              "SegmentationSubNet", "SqueezeExcite", "MobileSeparableConv2D", "DownSampleInput", "UpSampleOutput",
-             "TrimInstances", "SemanticSmoothing"]
+             "TrimInstances", "SemanticSmoothing", "CropAndPadMask", "CrackToInstance", "SummaryOutput",
+             "IncludeMyRoad", "CalculateInstanceSize"]
     reg = {n: getattr(L, n) for n in names}
     reg["BackBonePreProcess"] = BackBonePreProcess
     reg["GroupNormalization"] = GroupNormalization

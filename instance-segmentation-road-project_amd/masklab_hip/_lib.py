@@ -69,6 +69,10 @@ SIGNATURES = {
     "ml_upsample_boxes_i32": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "ml_threshold_i32": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
     "ml_semantic_smoothing_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 4 + [_vp, _vp, _vp]),
+    "ml_crop_pad_mask_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    "ml_nonzero_bbox_i32": (C.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),
+    "ml_instance_summary_workspace_bytes": (_i64, [_i32, _i32]),
+    "ml_instance_summary_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp] + [_i32] * 4 + [_f32, _f32, _vp, _vp]),
 }
 
 _lib = None

@@ -3,6 +3,6 @@ from .detection import *  # noqa: F401,F403
 from .detection import (BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, FeaturePyramid,
                         NormalizeBoxes, PriorLayer, RestoreBoxes)
 from .instance import MaskDistribute, MaskSubNet, PyramidRoiAlign, TrimInstances
-from .misc import (DownSampleInput, Identity, MobileSeparableConv2D, MoldBatch, ReLU, ResizeLike, SqueezeExcite,
-                   UpSampleOutput)
+from .misc import (CalculateInstanceSize, CrackToInstance, CropAndPadMask, DownSampleInput, Identity, IncludeMyRoad,
+                   MobileSeparableConv2D, MoldBatch, ReLU, ResizeLike, SqueezeExcite, SummaryOutput, UpSampleOutput)
 from .semantic import ASPPNetwork, AtrousSeparableConv2D, SegmentationSubNet, SemanticSmoothing

@@ -1,6 +1,8 @@
 """Misc layers of the hot path -- drop-ins for reference engine/layers/misc.py
 (Identity :206-210, ResizeLike :296-319, SqueezeExcite :24-54, MoldBatch :213-293) and of the
-deploy wrapper either side of it (DownSampleInput :143-154, UpSampleOutput :169-196)."""
+deploy wrapper either side of it (DownSampleInput :143-154, UpSampleOutput :169-196) and the arithmetic
+layers of the serving graph (CropAndPadMask :358-401, CrackToInstance :524-560, SummaryOutput :563-598,
+IncludeMyRoad :601-626, CalculateInstanceSize :629-727)."""
 import numpy as np
 import torch
 
@@ -221,3 +223,110 @@ class UpSampleOutput(Layer):
         semantic = ops.resize_image_ac(semantic_output, int(target_node.shape[1]), int(target_node.shape[2]),
                                        threshold=0.5)
         return boxes, masks, semantic
+
+
+# ----------------------------------------------------------------------------- serving post-processing
+class CropAndPadMask(Layer):
+    """Resize every kept instance mask to its box and pad it to the image (reference misc.py:358-401).
+    inputs = [images, det_outs int32 [B,n,6], ins_outs int32 [B,n,h,w], ...] -> float32 [B,n,H,W]."""
+
+    def call(self, inputs, **kwargs):
+        images, det_outs, ins_outs = inputs[0], inputs[1], inputs[2]
+        return ops.crop_pad_mask(det_outs.contiguous(), ins_outs.contiguous(), int(images.shape[1]), int(images.shape[2]))
+
+
+class CrackToInstance(Layer):
+    """Turn the crack channel of the semantic map into one pseudo instance (reference misc.py:524-560): the
+    bounding box of ALL non-zero pixels of the batch, class id 5, conf = clip(100 * h * w, 0, 100)."""
+
+    def __init__(self, crack_id=5, **kwargs):
+        self.crack_id = crack_id
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        # the reference passes seg_outs[..., 2] ([B,H,W]); `channel=` reads that slice of [B,H,W,C] in place
+        seg, channel = inputs, kwargs.get("channel")
+        if seg.dim() == 3:
+            seg, channel = seg[..., None].contiguous(), 0
+        elif channel is None:
+            raise ValueError("CrackToInstance: pass a [B,H,W] map, or a [B,H,W,C] map with channel=")
+        box = ops.nonzero_bbox(seg.contiguous(), channel).cpu().tolist()          # one small host read
+        ymin, xmin, ymax, xmax, any_ = box
+        if not any_:
+            ymin = xmin = ymax = xmax = 0                                       # tf.cond -> [[0, 0, 0]] (:534-536)
+        height, width = ymax - ymin, xmax - xmin
+        cy, cx = ymin + int(height / 2), xmin + int(width / 2)
+        conf = min(max(100 * height * width, 0), 100)
+        B = seg.shape[0]
+        row = torch.tensor([cx, cy, width, height, 5, conf], dtype=torch.int32, device=seg.device)   # `* 5`, as written (:546)
+        crack_det_outs = row[None, None, :].expand(B, 1, 6).contiguous()
+        crack_seg_outs = seg[..., channel].to(torch.float32)[:, None].contiguous()                  # data movement
+        return crack_det_outs, crack_seg_outs
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'crack_id': self.crack_id})
+        return config
+
+
+class IncludeMyRoad(Layer):
+    """Does an instance overlap the 'my road' class (reference misc.py:601-626)?  -> float32 [B,n] of 0 / 1."""
+
+    def __init__(self, threshold=0.1, **kwargs):
+        self.threshold = threshold
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        seg_outs, crop_ins_outs = inputs[0], inputs[1]
+        return ops.instance_summary(seg_outs.contiguous(), crop_ins_outs.contiguous(), 1, 3.25, self.threshold)[..., 4]
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'threshold': self.threshold})
+        return config
+
+
+class CalculateInstanceSize(Layer):
+    """Metric size of every instance from the road-width regression (reference misc.py:629-727)
+    -> float32 [B,n,3] = (instance_size, horizontal_size, vertical_size)."""
+
+    def __init__(self, default_road_size=3.25, **kwargs):
+        self.default_road_size = default_road_size
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        seg_outs, pad_ins_outs = inputs[0], inputs[1]
+        s = ops.instance_summary(seg_outs.contiguous(), pad_ins_outs.contiguous(), 1, self.default_road_size, 0.1)
+        return s[..., 1:4].contiguous()
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"default_road_size": self.default_road_size})
+        return config
+
+
+class SummaryOutput(Layer):
+    """The summary tensor of the serving model (reference misc.py:563-598): inputs = [det_outs int32 [B,n,6],
+    seg_outs int32 [B,H,W,3], crop_ins_outs float32 [B,n,H,W]] -> float32 [B,n',11] =
+    (class, cx, cy, w, h, conf, pixel count, instance size, horizontal size, vertical size, include_my_road);
+    n' = n + 1 when the crack channel yields a pseudo instance."""
+
+    def __init__(self, default_road_size=3.25, **kwargs):
+        self.default_road_size = default_road_size
+        super().__init__(**kwargs)
+
+    def call(self, inputs, **kwargs):
+        det_outs, seg_outs, crop_ins_outs = inputs[0], inputs[1], inputs[2]
+        crack_det_outs, crack_seg_outs = CrackToInstance()(seg_outs, channel=2)              # :575
+        if bool((crack_det_outs[..., -1] > 0).all()):                                        # :577-583
+            det_outs = torch.cat([det_outs, crack_det_outs], dim=1)
+            crop_ins_outs = torch.cat([crop_ins_outs, crack_seg_outs], dim=1)
+        s = ops.instance_summary(seg_outs.contiguous(), crop_ins_outs.contiguous(), 1, self.default_road_size, 0.1)
+        d = det_outs.to(torch.float32)
+        cx, cy, w, h, classes, conf = [d[..., i] for i in range(6)]
+        return torch.stack([classes, cx, cy, w, h, conf, s[..., 0], s[..., 1], s[..., 2], s[..., 3], s[..., 4]], dim=-1)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'default_road_size': self.default_road_size})
+        return config

@@ -465,3 +465,49 @@ def semantic_smoothing(x, kernel_sizes, weights):
         _lib.check(lib.ml_semantic_smoothing_f32(_ptr(x), _ptr(out), _ptr(tmp), B, H, W, Cc, ks, ws, _stream()),
                    "ml_semantic_smoothing_f32")
     return out
+
+
+# ----------------------------------------------------------------------------- serving post-processing
+def crop_pad_mask(det_outs, ins_outs, height, width):
+    """ml_crop_pad_mask_f32: det [B,n,6] int32, masks [B,n,mh,mw] int32 -> [B,n,H,W] float32."""
+    lib = _lib.load()
+    _require_dev(det_outs, "det_outs")
+    _require_dev(ins_outs, "ins_outs")
+    if det_outs.dtype != torch.int32 or ins_outs.dtype != torch.int32:
+        raise RuntimeError("crop_pad_mask: int32 detections and masks expected (UpSampleOutput's outputs)")
+    B, n, _ = det_outs.shape
+    _, _, mh, mw = ins_outs.shape
+    out = torch.empty((B, n, height, width), dtype=torch.float32, device=det_outs.device)
+    thr = torch.empty((1,), dtype=torch.int32, device=det_outs.device)
+    with _Prof("crop_pad_mask", 0, 4 * (out.numel() + ins_outs.numel())):
+        _lib.check(lib.ml_crop_pad_mask_f32(_ptr(det_outs), _ptr(ins_outs), _ptr(out), _ptr(thr), B, n, mh, mw,
+                                            int(height), int(width), _stream()), "ml_crop_pad_mask_f32")
+    return out
+
+
+def nonzero_bbox(seg, channel):
+    """ml_nonzero_bbox_i32 -> int32 [5] = (ymin, xmin, ymax, xmax, any) over the whole batch."""
+    lib = _lib.load()
+    _require_dev(seg, "seg")
+    B, H, W, Cc = seg.shape
+    box = torch.tensor([2 ** 31 - 1, 2 ** 31 - 1, -1, -1, 0], dtype=torch.int32, device=seg.device)
+    _lib.check(lib.ml_nonzero_bbox_i32(_ptr(seg), B, H, W, Cc, int(channel), _ptr(box), _stream()), "ml_nonzero_bbox_i32")
+    return box
+
+
+def instance_summary(seg, masks, road_channel=1, default_road_size=3.25, ioi_threshold=0.1):
+    """ml_instance_summary_f32 -> [B,n,5] = (pixel sum, instance size, horizontal, vertical, include_my_road)."""
+    lib = _lib.load()
+    _require_dev(seg, "seg")
+    _require_dev(masks, "masks")
+    if seg.dtype != torch.int32 or masks.dtype != torch.float32:
+        raise RuntimeError("instance_summary: int32 semantic map and float32 padded masks expected")
+    B, H, W, Cc = seg.shape
+    _, n, _, _ = masks.shape
+    out = torch.empty((B, n, 5), dtype=torch.float32, device=seg.device)
+    ws = workspace(int(lib.ml_instance_summary_workspace_bytes(B, H)), seg.device, "summary")
+    with _Prof("instance_summary", 0, 4 * (2 * masks.numel() + 2 * seg.numel())):
+        _lib.check(lib.ml_instance_summary_f32(_ptr(seg), Cc, int(road_channel), _ptr(masks), _ptr(out), B, n, H, W,
+                                               float(default_road_size), float(ioi_threshold), _ptr(ws), _stream()),
+                   "ml_instance_summary_f32")
+    return out

@@ -586,3 +586,109 @@ def deploy_forward(config, weights, images, **kw):
     post = np.concatenate([semantic_smoothing(t, k, w_) for t, k, w_ in zip(parts, ks, ws)], axis=-1)
     sem = T.resize_bilinear_align_corners(post, down.shape[1], down.shape[2])          # :628
     return up_sample_output(det, inst, sem, images.shape[1:3])            # :634-635
+
+
+# ----------------------------------------------------------------------------- serving post-processing
+def crop_and_pad_mask(images_hw, det_outs, ins_outs):
+    """CropAndPadMask.call, engine/layers/misc.py:358-401.  det_outs int32 [B,n,6], ins_outs int32 [B,n,h,w]."""
+    image_h, image_w = int(images_hw[0]), int(images_hw[1])
+    B, n, _ = det_outs.shape
+    threshold = 50 if det_outs[..., -1].max() > 50 else -100                       # :371-374
+    out = np.zeros((B, n, image_h, image_w), F32)                                  # :396-398 scatter_nd into zeros
+    for b, i in np.argwhere(det_outs[..., -1] >= threshold):                       # :375
+        box = np.maximum(det_outs[b, i], 1).astype(F32)                            # :379, :382
+        cx, cy, w, h = box[0], box[1], box[2], box[3]
+        xmin = int(np.clip(np.int32(np.ceil(cx - w / F32(2))), 0, image_w))        # :384-391
+        xmax = int(np.clip(np.int32(np.ceil(cx + w / F32(2))), 0, image_w))
+        ymin = int(np.clip(np.int32(np.ceil(cy - h / F32(2))), 0, image_h))
+        ymax = int(np.clip(np.int32(np.ceil(cy + h / F32(2))), 0, image_h))
+        if ymax - ymin <= 0 or xmax - xmin <= 0:
+            continue                                       # tf.image.resize to a zero size raises in the reference
+        m = ins_outs[b, i].astype(F32)[None, :, :, None]
+        r = T.resize_bilinear_align_corners(m, ymax - ymin, xmax - xmin)[0, :, :, 0]   # :393-395
+        out[b, i, ymin:ymax, xmin:xmax] = r                                        # tf.pad (:396)
+    return out
+
+
+def crack_to_instance(crack):
+    """CrackToInstance.call, engine/layers/misc.py:533-560.  crack int32 [B,H,W]."""
+    idx = np.argwhere(crack)                                                       # :533
+    if idx.size == 0:
+        idx = np.zeros((1, 3), np.int64)                                           # :534-536
+    ymin, xmin = idx.min(axis=0)[1:]
+    ymax, xmax = idx.max(axis=0)[1:]
+    height, width = np.int32(ymax - ymin), np.int32(xmax - xmin)
+    cy = np.int32(ymin) + np.int32(height / 2)                                     # :542-543 (float division, then cast)
+    cx = np.int32(xmin) + np.int32(width / 2)
+    conf = np.int32(np.clip(100 * int(height) * int(width), 0, 100))               # :545
+    row = np.asarray([cx, cy, width, height, 5, conf], np.int32)                   # `ones_like(cx) * 5` (:544)
+    det = np.tile(row[None, None, :], (crack.shape[0], 1, 1))                      # :547-550
+    return det, crack[:, None].astype(F32)                                         # :551
+
+
+def _road_unit_length(image, default_road_size):
+    """CalculateInstanceSize._calculate_road_size_by_vertical_per_batch, misc.py:663-679.  image [H,W] int32."""
+    H = image.shape[0]
+    idx = np.argwhere(image > 0)                                                   # :664
+    ys, xs = idx[:, 0], idx[:, 1]
+    n_seg = int(ys.max()) + 1 if len(ys) else 0
+    x_mins = np.zeros(n_seg, np.int64)                                             # tf.segment_min / max: empty segment -> 0
+    x_maxs = np.zeros(n_seg, np.int64)
+    for y in np.unique(ys):
+        row = xs[ys == y]
+        x_mins[y], x_maxs[y] = row.min(), row.max()                                # :683-684
+    y_pos = np.arange(n_seg, dtype=np.int64)
+    keep = x_mins != x_maxs                                                        # :687-692
+    left = np.stack([y_pos, x_mins], -1)[keep]
+    right = np.stack([y_pos, x_maxs], -1)[keep]
+    valid = F32(len(left))
+    drop = int(np.clip(np.int32(valid * F32(0.15)), 1, 2 ** 31 - 1))               # :695-697
+    left = left[drop:-drop].astype(F32)                                            # :699-702
+    right = right[drop:-drop].astype(F32)
+
+    def theta(pos):                                                                # :705-717
+        xs_ = np.stack([pos[:, 0], np.ones_like(pos[:, 0])], axis=1).astype(F32)
+        ys_ = pos[:, 1:2].astype(F32)
+        x_mat = (xs_.T @ xs_).astype(F32)
+        if np.linalg.det(x_mat.astype(F32)) > 0:
+            return (np.linalg.inv(x_mat).astype(F32) @ (xs_.T @ ys_)).astype(F32)
+        return np.zeros((2, 1), F32)
+
+    lt, rt = theta(left), theta(right)
+    y = np.arange(H, dtype=F32)
+    width = np.clip((y * rt[0] + rt[1]) - (y * lt[0] + lt[1]), F32(1), np.inf).astype(F32)    # :672-677
+    return (F32(default_road_size) / width).astype(F32)                            # :678
+
+
+def calculate_instance_size(seg_outs, pad_ins_outs, default_road_size=3.25):
+    """CalculateInstanceSize.call, engine/layers/misc.py:637-661 -> [B,n,3] (instance, horizontal, vertical)."""
+    unit = np.stack([_road_unit_length(seg_outs[b, ..., 1], default_road_size) for b in range(seg_outs.shape[0])])   # :642-644
+    m = pad_ins_outs.astype(F32)
+    inst = ((unit ** 2)[:, None, :, None] * m).sum(axis=(2, 3))                    # :647-650
+    vert = (unit[:, None, :] * (m > 0.5).any(axis=-1).astype(F32)).sum(axis=-1)    # :652-655
+    horiz = (unit[:, None, :, None] * m).sum(axis=2).max(axis=-1)                  # :657-659
+    return np.stack([inst, horiz, vert], axis=-1).astype(F32)
+
+
+def include_my_road(seg_outs, crop_ins_outs, threshold=0.1):
+    """IncludeMyRoad.call, engine/layers/misc.py:609-618."""
+    my_road = seg_outs[..., 1].astype(F32)
+    m = crop_ins_outs.astype(F32)
+    inter = np.logical_and((my_road > 0.5)[:, None], m > 0.5).astype(F32).sum(axis=(2, 3))
+    area = (m > 0.5).astype(F32).sum(axis=(2, 3))
+    return ((inter / (area + F32(1e-5))) > F32(threshold)).astype(F32)
+
+
+def summary_output(det_outs, seg_outs, crop_ins_outs, default_road_size=3.25):
+    """SummaryOutput.call, engine/layers/misc.py:569-598 -> [B,n',11]."""
+    crack_det, crack_seg = crack_to_instance(seg_outs[..., 2])                     # :575
+    if np.all(crack_det[..., -1] > 0):                                             # :577-583
+        det_outs = np.concatenate([det_outs, crack_det], axis=1)
+        crop_ins_outs = np.concatenate([crop_ins_outs, crack_seg], axis=1)
+    d = det_outs[..., :6].astype(F32)
+    cx, cy, w, h, classes, conf = [d[..., i] for i in range(6)]                    # :585-586
+    pixel_counts = crop_ins_outs.astype(F32).sum(axis=(2, 3))                      # :588-589
+    sizes = calculate_instance_size(seg_outs, crop_ins_outs, default_road_size)    # :591-593
+    inc = include_my_road(seg_outs, crop_ins_outs)                                 # :595
+    return np.stack([classes, cx, cy, w, h, conf, pixel_counts, sizes[..., 0], sizes[..., 1], sizes[..., 2], inc],
+                    axis=-1).astype(F32)                                           # :597-598

@@ -160,8 +160,12 @@ def test_deploy_layers_config_and_registry():
     import masklab_hip as M
     from masklab_hip import layers as L
     reg = M.get_custom_objects()
-    for name in ("DownSampleInput", "UpSampleOutput", "TrimInstances", "SemanticSmoothing"):
+    for name in ("DownSampleInput", "UpSampleOutput", "TrimInstances", "SemanticSmoothing", "CropAndPadMask",
+                 "CrackToInstance", "SummaryOutput", "IncludeMyRoad", "CalculateInstanceSize"):
         assert reg[name] is getattr(L, name)
+    assert L.SummaryOutput().get_config()["default_road_size"] == 3.25             # reference misc.py:567
+    assert L.CalculateInstanceSize().get_config()["default_road_size"] == 3.25
+    assert L.IncludeMyRoad().get_config()["threshold"] == 0.1 and L.CrackToInstance().get_config()["crack_id"] == 5
     assert L.DownSampleInput().get_config()["target_size"] == (540, 960)          # reference misc.py:141
     assert L.TrimInstances().get_config()["mold"] is True and L.TrimInstances().get_config()["max_batch_size"] == 64
     c = L.SemanticSmoothing().get_config()

@@ -366,3 +366,62 @@ def test_detection_iou_metric_restatement():
     empty = np.full((1, 2, 6), -1, np.float32)
     p, r, f = M.detection_iou_metric(empty, empty)
     assert p[0] == 0 and r[0] == 0 and f[0] == 0
+
+
+# ----------------------------------------------------------------------------- serving post-processing
+def test_crop_and_pad_mask_hand_case():
+    det = np.array([[[6, 5, 4, 2, 1, 90], [3, 3, 2, 2, 0, 40]]], np.int32)        # second row below the conf-50 cut
+    ins = np.zeros((1, 2, 2, 2), np.int32)
+    ins[0, 0] = [[1, 0], [0, 1]]
+    ins[0, 1] = 1
+    out = O.crop_and_pad_mask((8, 10), det, ins)
+    assert out.shape == (1, 2, 8, 10) and out.dtype == np.float32
+    # box 0: x in [ceil(6-2), ceil(6+2)) = [4, 8), y in [ceil(5-1), ceil(5+1)) = [4, 6): the 2x2 mask resized to 2x4
+    want = np.zeros((8, 10), np.float32)
+    want[4, 4:8] = [1, 2 / 3, 1 / 3, 0]
+    want[5, 4:8] = [0, 1 / 3, 2 / 3, 1]
+    np.testing.assert_allclose(out[0, 0], want, atol=1e-6)
+    assert out[0, 1].max() == 0                                                  # not selected
+    det[0, 0, 5] = 45                                                            # nothing above 50 -> every row is kept
+    out = O.crop_and_pad_mask((8, 10), det, ins)
+    assert out[0, 1, 2:4, 2:4].min() == 1 and out[0, 1].sum() == 4
+
+
+def test_crack_to_instance_and_summary_columns():
+    seg = np.zeros((2, 12, 16, 3), np.int32)
+    seg[0, 3:7, 4:10, 2] = 1                                                     # crack pixels: y 3..6, x 4..9
+    seg[1, 8, 12, 2] = 1                                                         # the bounding box spans the BATCH
+    det, cseg = O.crack_to_instance(seg[..., 2])
+    # ymin 3, ymax 8, xmin 4, xmax 12 -> h 5, w 8, cy 3 + 2, cx 4 + 4, conf clip(100*5*8) = 100
+    np.testing.assert_array_equal(det[:, 0], [[8, 5, 8, 5, 5, 100]] * 2)
+    assert cseg.shape == (2, 1, 12, 16) and cseg.sum() == 25
+    det0 = np.array([[[8, 6, 4, 4, 2, 80]], [[8, 6, 4, 4, 2, 80]]], np.int32)
+    masks = np.zeros((2, 1, 12, 16), np.float32)
+    masks[:, 0, 4:8, 6:10] = 1
+    seg[:, 2:11, 5:11, 1] = 1                                                    # a straight road, 6 px wide: x 5..10
+    out = O.summary_output(det0, seg, masks, default_road_size=3.0)
+    assert out.shape == (2, 2, 11)
+    np.testing.assert_array_equal(out[0, 0, :7], [2, 8, 6, 4, 4, 80, 16])        # class, cx, cy, w, h, conf, pixels
+    # edges: left x = 5, right x = 10 for every kept row -> width 5 -> unit 0.6; 16 px * 0.36, 4 rows * 0.6, 4 px * 0.6
+    np.testing.assert_allclose(out[0, 0, 7:10], [16 * 0.36, 4 * 0.6, 4 * 0.6], rtol=1e-4)
+    assert out[0, 0, 10] == 1 and out[0, 1, 0] == 5                              # on the road; crack pseudo instance appended
+    none = O.summary_output(det0, np.zeros_like(seg), masks)
+    assert none.shape == (2, 1, 11)                                              # no crack pixels: nothing appended
+    np.testing.assert_allclose(none[0, 0, 7:10], [16 * 3.25 ** 2, 4 * 3.25, 4 * 3.25], rtol=1e-6)   # no road: width clipped to 1
+
+
+def test_road_regression_matches_float64_least_squares():
+    """the float32 normal-equation solve of the reference against numpy's float64 lstsq on a clean trapezoid"""
+    H, W = 200, 300
+    img = np.zeros((H, W), np.int32)
+    for y in range(40, 190):
+        img[y, int(100 - 0.3 * (y - 40)):int(180 + 0.4 * (y - 40))] = 1
+    unit = O._road_unit_length(img, 3.25)
+    ys = np.arange(40, 190)[22:-22].astype(np.float64)                          # 15 % of 150 rows dropped at both ends
+    lx = np.array([np.nonzero(img[int(y)])[0].min() for y in ys], np.float64)
+    rx = np.array([np.nonzero(img[int(y)])[0].max() for y in ys], np.float64)
+    A = np.stack([ys, np.ones_like(ys)], 1)
+    lt, rt = np.linalg.lstsq(A, lx, rcond=None)[0], np.linalg.lstsq(A, rx, rcond=None)[0]
+    y = np.arange(H)
+    want = 3.25 / np.clip((y * rt[0] + rt[1]) - (y * lt[0] + lt[1]), 1, np.inf)
+    np.testing.assert_allclose(unit, want, rtol=2e-3)
