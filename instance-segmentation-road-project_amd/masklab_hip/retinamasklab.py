@@ -12,7 +12,8 @@ import torch
 from . import backbone
 from . import keras_like as K
 from .config import ModelConfiguration
-from .layers import (ASPPNetwork, BoxRegressionSubNet, ClassificationSubNet, DetectionProposal, DownSampleInput,
+from .layers import (ASPPNetwork, BoxRegressionSubNet, ClassificationSubNet, CropAndPadMask, DetectionProposal,
+                     DownSampleInput, SummaryOutput,
                      FeaturePyramid, MaskDistribute, MaskSubNet, PriorLayer, PyramidRoiAlign, ResizeLike,
                      RestoreBoxes, SegmentationSubNet, SemanticSmoothing, TrimInstances, UpSampleOutput)
 from .prior import PriorBoxes
@@ -381,6 +382,39 @@ class DeployModel(K.Layer):
 def construct_deploy_network(configuration: ModelConfiguration, inference_model):
     """Wrap an inference model like reference :598-643 (serving=False)."""
     return DeployModel(configuration, inference_model)
+
+
+class ServingModel(K.Layer):
+    """The arithmetic half of reference road_project/setup/serving.py:16-52 (`load_serving_model_from_h5`):
+    deploy model -> CropAndPadMask -> SummaryOutput.  Returns the 'summarize' tensor float32 [B,n',11]
+    (class, cx, cy, w, h, conf, pixel count, instance size, horizontal size, vertical size, include_my_road).
+    The 'visualize' output (DrawBoxes / DrawInstance / DrawSegmentation / JPEG encode, :32-40) and the JPEG
+    decode in front are image I/O, not arithmetic of this path, and are not built."""
+
+    def __init__(self, configuration, deploy_model, name='serving'):
+        super().__init__(name=name)
+        self.deploy_model = deploy_model
+        self.crop_and_pad = CropAndPadMask()
+        self.summary = SummaryOutput(default_road_size=configuration.postprocess.default_road_size)
+        self.output_names = ['summarize']
+        self.built = True
+
+    def call(self, images, **kwargs):
+        if not isinstance(images, torch.Tensor):
+            images = torch.as_tensor(np.asarray(images))
+        images = images.to(self.deploy_model.model.device).contiguous()
+        det_outs, ins_outs, seg_outs = self.deploy_model(images)                            # :27-29
+        crop_and_pad_masks = self.crop_and_pad([images, det_outs, ins_outs, seg_outs])      # :30
+        return self.summary([det_outs, seg_outs, crop_and_pad_masks])                       # :47-48
+
+    def predict(self, images, **kwargs):
+        out = self.call(images, **kwargs)
+        torch.cuda.synchronize(self.deploy_model.model.device)
+        return out.cpu().numpy()
+
+
+def construct_serving_network(configuration: ModelConfiguration, deploy_model):
+    return ServingModel(configuration, deploy_model)
 
 
 def load_masklab_inference_model_from_weights(weights, config: ModelConfiguration, device="cuda"):

@@ -692,3 +692,11 @@ def summary_output(det_outs, seg_outs, crop_ins_outs, default_road_size=3.25):
     inc = include_my_road(seg_outs, crop_ins_outs)                                 # :595
     return np.stack([classes, cx, cy, w, h, conf, pixel_counts, sizes[..., 0], sizes[..., 1], sizes[..., 2], inc],
                     axis=-1).astype(F32)                                           # :597-598
+
+
+def serving_forward(config, weights, images, **kw):
+    """The 'summarize' output of load_serving_model_from_h5, road_project/setup/serving.py:27-48."""
+    images = np.asarray(images)
+    det, inst, sem = deploy_forward(config, weights, images, **kw)                 # :24-29
+    masks = crop_and_pad_mask(images.shape[1:3], det, inst)                        # :30
+    return summary_output(det, sem, masks, config.postprocess.default_road_size)  # :47-48

@@ -99,3 +99,27 @@ def test_instance_size_without_any_road():
     got = host(CalculateInstanceSize(3.25)([dev(seg), dev(masks)]))
     np.testing.assert_allclose(got, want, rtol=1e-5)
     np.testing.assert_array_equal(host(IncludeMyRoad()([dev(seg), dev(masks)])), O.include_my_road(seg, masks))
+
+
+def test_serving_model_end_to_end():
+    """uint8 images -> deploy model -> CropAndPadMask -> SummaryOutput against the oracle's serving_forward."""
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = "mobilenet"
+    cfg.postprocess.resolution = (128, 256)
+    _, model = R.construct_masklab_networks(cfg)
+    w = model.init_weights(3)
+    for k in w:
+        if k.startswith("classification_sub_net/") and k.endswith("/output/kernel"):
+            w[k] = (w[k] * 8.0).astype(np.float32)
+    model.load_weights(w, "cuda:0")
+    serving = R.construct_serving_network(cfg, R.construct_deploy_network(cfg, model))
+    images = np.random.default_rng(1234).integers(0, 256, (2, 320, 640, 3), dtype=np.uint8)
+    got = serving.predict(images)
+    want = O.serving_forward(cfg, w, images, literal_groups=False)
+    assert got.shape == want.shape and got.shape[-1] == 11
+    np.testing.assert_array_equal(got[..., 0], want[..., 0])                     # classes / padding rows
+    assert np.abs(got[..., 1:6] - want[..., 1:6]).max() <= 1                     # int-truncated boxes (see test_gpu_deploy)
+    # areas follow the thresholded masks: a flipped mask pixel changes a count by one
+    np.testing.assert_allclose(got[..., 6], want[..., 6], rtol=2e-3, atol=2)
+    np.testing.assert_allclose(got[..., 7:10], want[..., 7:10], rtol=1e-2, atol=1e-2 * max(1.0, float(want[..., 7:10].max())))
