@@ -125,6 +125,126 @@ gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, 
     }
 }
 
+// ---- c = 16: one group is a full 16 x 16 block, so v_mfma_f32_16x16x4_f32 wastes nothing either and needs a
+// quarter of the operand traffic per flop: D[out 16][pixel 16] += W[out][in 4] * X[in 4][pixel].
+//   A: lane (i = l & 15, q = l >> 4) holds W[out i][in 4q + s] for k-step s   (9 float4 per lane, in registers)
+//   B: lane (j = l & 15, q)          holds X[pixel j][in 4q + s]              (one ds_read_b128 per tap)
+//   D: lane (j, q) holds out channels 4q .. 4q+3 of pixel j                   (one float4 store)
+// (the MFMA's k index is permuted -- lane quarter q, step s <-> channel 4q + s -- identically for A and B.)
+// Wave w of the block owns group w of the 64-channel slab and walks the tile's 16-pixel sets.
+constexpr int PS16 = 68;   // LDS floats per pixel: 16 consecutive pixels x 16 B land on 64 distinct banks
+
+template <int STRIDE, int TH, int TW>
+__global__ void __launch_bounds__(256)
+gconv16_kernel(const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+               float *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+    constexpr int THIN = (TH - 1) * STRIDE + 3;
+    constexpr int TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int NPIX = THIN * TWIN;
+    constexpr int NLD = (NPIX + 15) / 16;
+    constexpr int SETS = TH * TW / 16;          // 16-pixel sets per tile: two output rows of 8
+    static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
+    extern __shared__ __align__(16) float tile[];   // [NPIX][PS16]
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+
+    f32x4 stage[NLD];
+    {
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = (tid >> 4) + 16 * i;
+            const int py = p / TWIN, px = p - py * TWIN;
+            const int iy = iy0 + py, ix = ix0 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f32x4 *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+            stage[i] = v;
+        }
+    }
+    // weights of group `wave`: out channel cs0 + 16 wave + j, taps 0..8, in channels 4q..4q+3
+    f32x4 wv[9];
+    {
+        const float *wrow = wgt + (long long)(cs0 + wave * 16 + j) * 9 * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(wrow + t * 16);
+    }
+    {
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = (tid >> 4) + 16 * i;
+            if (p < NPIX) *reinterpret_cast<f32x4 *>(tile + p * PS16 + c4) = stage[i];
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[SETS];
+    int pbase[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int py = 2 * s + (j >> 3), px = j & 7;            // output pixel of this lane in set s
+        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16 + wave * 16 + 4 * q;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * TWIN + (t % 3)) * PS16;
+        f32x4 xv[SETS];
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) xv[s] = *reinterpret_cast<const f32x4 *>(tile + pbase[s] + toff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < SETS; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], xv[s][e], acc[s], 0, 0, 0);
+    }
+
+    const int oc = cs0 + wave * 16 + 4 * q;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
+        if (oy >= Ho || ox >= Wo) continue;
+        const f32x4 v = acc[s] + bv;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+        *reinterpret_cast<f32x4 *>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc) = r;
+    }
+}
+
+template <int STRIDE, int TH, int TW>
+int launch16(const float *in, const float *wgt, const float *bias, float *out, int B, int H, int W, int C, int Ho, int Wo,
+             int pad_t, int pad_l, int act, hipStream_t s) {
+    constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int LDS_BYTES = THIN * TWIN * PS16 * 4;
+    auto kern = gconv16_kernel<STRIDE, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            ml_set_error("gconv3x3: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
+            return ML_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho,
+                       Wo, pad_t, pad_l, act, tiles_x);
+    ML_CHECK_LAUNCH("gconv3x3");
+    return ML_OK;
+}
+
 template <int STRIDE, int TH, int TW, int CPG>
 int launch(const float *in, const float *wgt, const float *bias, float *out, int B, int H, int W, int C, int Ho,
            int Wo, int pad_t, int pad_l, int act, hipStream_t s) {
@@ -168,10 +288,10 @@ extern "C" int ml_gconv3x3_f32(const float *in, const float *wgt, const float *b
     if (stride == 1) {
         if (c == 4) return launch<1, 8, 8, 4>(GC_ARGS);
         if (c == 8) return launch<1, 8, 8, 8>(GC_ARGS);
-        return launch<1, 8, 8, 16>(GC_ARGS);
+        return launch16<1, 8, 8>(GC_ARGS);
     }
     if (c == 4) return launch<2, 4, 8, 4>(GC_ARGS);
     if (c == 8) return launch<2, 4, 8, 8>(GC_ARGS);
-    return launch<2, 4, 8, 16>(GC_ARGS);
+    return launch16<2, 4, 8>(GC_ARGS);
 #undef GC_ARGS
 }
