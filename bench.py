@@ -200,6 +200,8 @@ def main():
     images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
     if args.graph:
         model.enable_graphs(True)
+    if os.environ.get("MASKLAB_SIDE_STREAM") == "0":       # A/B knob; the model's default is on
+        model.use_side_stream = False
 
     def mark(msg):
         if rehearsal:

@@ -71,8 +71,9 @@ def _require_dev(t, name):
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag); 256-byte aligned by the torch allocator."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer per (device, tag, stream); 256-byte aligned by the torch allocator.
+    Keyed by the launch stream too: work enqueued on two streams must not share scratch memory."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -127,6 +127,8 @@ class InferenceModel(K.Layer):
         self.last_detections = None
         self._use_graphs = False
         self._graphs = {}
+        self.use_side_stream = True       # semantic head on a second HIP stream beside FPN / towers / detection
+        self._side_stream = None
         self._build_shapes()
 
     # ---- structure
@@ -207,6 +209,20 @@ class InferenceModel(K.Layer):
             aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
             return seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]])
 
+        # The semantic head only needs backbone taps: with `use_side_stream` it is enqueued on a second HIP stream
+        # right after the backbone, so its low-occupancy launches (ASPP on the 1/32 map) and the detection
+        # post-processing (40 + 8 blocks) fill each other's idle CUs.  Joined before stage 1 returns.
+        side = None
+        if self.semantic_networks is not None and getattr(self, "use_side_stream", False):
+            from . import ops as _ops
+            if _ops.PROFILE is None:
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=self.device)
+                side = self._side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    st["seg_pred"] = semantic_head()
         if self.detection_networks is not None:
             det_config = cfg.detection
             prior_subnet, fpn_subnet, cls_subnet, loc_subnet = self.detection_networks
@@ -230,7 +246,10 @@ class InferenceModel(K.Layer):
                                                               base_size=distribute_subnet.base_size)
                 st.update(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes, slots=slots,
                           lcounts=lcounts, roi_features=feature_outputs[:n_levels])
-        if self.semantic_networks is not None:
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            st["seg_pred"].record_stream(torch.cuda.current_stream())
+        elif self.semantic_networks is not None:
             # independent of the instance branch and enqueued BEFORE the host reads the RoI counts, so the
             # GPU stays busy while the host waits (same stream, same results)
             st["seg_pred"] = semantic_head()

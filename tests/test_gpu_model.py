@@ -231,3 +231,28 @@ def test_more_than_32_images_is_refused_like_the_reference():
     images = np.zeros((33, 128, 128, 3), np.uint8)
     with pytest.raises(ValueError, match="32"):
         model.predict(images)
+
+
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50"])
+def test_side_stream_semantic_head_is_bit_identical(bt):
+    """use_side_stream: the semantic head runs on a second HIP stream beside FPN / towers / detection (own scratch
+    buffers per stream, joined before stage 1 returns) -- same kernels, same inputs, so the same bits; also under
+    hipGraph capture (the side stream forks from and joins the capturing stream)."""
+    cfg, model, w = _build(bt, seed=5, hot_cls=True)
+    rng = np.random.default_rng(17)
+    imgs = [rng.integers(0, 256, (2, 128, 256, 3), dtype=np.uint8) for _ in range(3)]
+    model.use_side_stream = False
+    want = [model.predict(im) for im in imgs]
+    model.use_side_stream = True
+    for rep in range(3):
+        for im, ref in zip(imgs, want):
+            got = model.predict(im)
+            for name, g, r in zip(model.output_names, got, ref):
+                np.testing.assert_array_equal(g, r, err_msg=f"{name} (side stream, pass {rep})")
+    model.enable_graphs(True)
+    for rep in range(2):
+        for im, ref in zip(imgs, want):
+            got = model.predict(im)
+            for name, g, r in zip(model.output_names, got, ref):
+                np.testing.assert_array_equal(g, r, err_msg=f"{name} (side stream + graph, pass {rep})")
+    model.enable_graphs(False)
