@@ -209,20 +209,26 @@ class InferenceModel(K.Layer):
             aspp_outputs = aspp_subnet(by_name[seg_config.aspp_input_name])
             return seg_subnet([aspp_outputs, by_name[seg_config.skip_input_name]])
 
-        # The semantic head only needs backbone taps: with `use_side_stream` it is enqueued on a second HIP stream
-        # right after the backbone, so its low-occupancy launches (ASPP on the 1/32 map) and the detection
-        # post-processing (40 + 8 blocks) fill each other's idle CUs.  Joined before stage 1 returns.
+        # The semantic head only needs backbone taps.  With `use_side_stream` it goes to a second HIP stream, enqueued
+        # once the towers are queued: it then runs beside the detection post-processing (40 + 8 blocks), through
+        # the host's read of the RoI counts and its preparation of stage 2 (~0.2 ms during which the main stream is
+        # empty), and beside the first mask-head launches.  Joined at the end of stage 2 (of stage 1 under capture).
         side = None
-        if self.semantic_networks is not None and getattr(self, "use_side_stream", False):
+
+        def launch_semantic_on_side():
             from . import ops as _ops
-            if _ops.PROFILE is None:
-                main = torch.cuda.current_stream()
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=self.device)
-                side = self._side_stream
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    st["seg_pred"] = semantic_head()
+            if self.semantic_networks is None or not getattr(self, "use_side_stream", False) or _ops.PROFILE is not None:
+                return None
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                st["seg_pred"] = semantic_head()
+            return self._side_stream
+
+        if self.detection_networks is None:
+            side = launch_semantic_on_side()
         if self.detection_networks is not None:
             det_config = cfg.detection
             prior_subnet, fpn_subnet, cls_subnet, loc_subnet = self.detection_networks
@@ -232,6 +238,7 @@ class InferenceModel(K.Layer):
             feature_outputs = fpn_subnet(fpn_inputs) + without_fpn
             st["cls_pred"] = cls_subnet(feature_outputs)
             st["loc_pred"] = loc_subnet(feature_outputs)
+            side = launch_semantic_on_side()
             if self.instance_networks is not None:
                 restore_subnet, distribute_subnet, pyramid_roi_align, _ = self.instance_networks
                 restored_boxes = restore_subnet([st["loc_pred"], pr_boxes])
@@ -247,13 +254,22 @@ class InferenceModel(K.Layer):
                 st.update(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes, slots=slots,
                           lcounts=lcounts, roi_features=feature_outputs[:n_levels])
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            st["seg_pred"].record_stream(torch.cuda.current_stream())
+            st["side"] = side
+            st["keepalive"] = by_name            # backbone taps the side stream still reads
+            if torch.cuda.is_current_stream_capturing():
+                self._join_side(st)              # a captured stage 1 must be self-contained
         elif self.semantic_networks is not None:
             # independent of the instance branch and enqueued BEFORE the host reads the RoI counts, so the
             # GPU stays busy while the host waits (same stream, same results)
             st["seg_pred"] = semantic_head()
         return st
+
+    def _join_side(self, st):
+        side = st.pop("side", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            st["seg_pred"].record_stream(torch.cuda.current_stream())
+            st.pop("keepalive", None)
 
     def _stage2(self, st):
         outputs = []
@@ -267,6 +283,7 @@ class InferenceModel(K.Layer):
                 outputs += [roi_boxes, roi_masks]
                 self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"],
                                             boxes=st["boxes"])
+        self._join_side(st)
         if self.semantic_networks is not None:
             outputs.append(st["seg_pred"])
         return outputs
@@ -288,7 +305,7 @@ class InferenceModel(K.Layer):
         if entry is None:
             if ops.PROFILE is not None:
                 raise RuntimeError("graph capture cannot run under the per-launch profiling hook")
-            self._stage1(images)                     # warm-up: fills the anchor / workspace caches, sets kernel attributes
+            self._join_side(self._stage1(images))    # warm-up: fills the anchor / workspace caches, sets kernel attributes
             torch.cuda.synchronize(self.device)
             static_in = images.clone()
             graph = torch.cuda.CUDAGraph()
