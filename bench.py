@@ -315,7 +315,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 MFMA operands, f32 accumulate, f32 tensors" if f16 else "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "backbone": backbone, "per_gpu_batch": B, "global_batch": B * world,
+            "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world,
                        "height": H, "width": W, "parallelism": f"dp{world}", "hipgraph": bool(args.graph),
                        "weights": "random init (cls logits x8 so NMS / mask head run at full load)",
                        "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
