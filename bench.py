@@ -305,10 +305,10 @@ def main():
         cpu, parity = cpu_baseline(cfg, weights, first.cpu().numpy(), gpu_first, gpu_kept)
 
     if rank == 0:
+        thr = cfg.detection.min_confidence
+        outs = model(images)                    # the full bench batch again (the parity leg ran a single image)
         det = model.last_detections
         n_det = det["counts"].cpu().tolist() if det else []
-        thr = cfg.detection.min_confidence
-        outs = model(images)
         n_cand = (outs[0] >= thr).sum(dim=(1, 2)).cpu().tolist() if det else []
         total_images = B * world * args.steps
         line = {
