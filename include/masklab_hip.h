@@ -15,7 +15,9 @@
  *     write a slice of a concat buffer without a copy);
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work;
  *   - return value: 0 = ok, negative = ML_E_* (no exceptions cross the boundary);
- *   - thread-safe per stream, no global mutable state besides the error string.
+ *   - thread-safe per stream; the only global state is the per-thread error string and, per
+ *     kernel, an atomic bitmask of the devices whose dynamic-LDS limit has been raised
+ *     (hipFuncSetAttribute is a per-device setting; racing threads set the same value).
  */
 #ifndef MASKLAB_HIP_H
 #define MASKLAB_HIP_H
@@ -34,7 +36,9 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1 };
 
-#define ML_ABI_VERSION 2              /* 2: ml_conv2d_desc gained `math` / `reserved0`     */
+#define ML_ABI_VERSION 3              /* 2: ml_conv2d_desc gained `math` / `reserved0`
+                                         3: detection gather payload, mask_distribute level_max,
+                                            conv GroupNorm-statistics epilogue, fp16 tensor storage   */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -158,21 +162,29 @@ int ml_restore_boxes_f32(const float *loc, const int32_t *priors, float *boxes,
 /* DetectionProposal (detection.py:482-567) in fixed capacity: threshold -> per-(image,class)
  * greedy NMS -> per-image cross-class NMS -> rows (cx,cy,w,h,class,conf), -1 padded.
  *   cls_pred [B,A,C], boxes [B,A,4] -> proposed [B,max_out,6], counts [B] (int32),
- *   kept [B,max_out,2] (anchor, class) int32 or NULL.
+ *   kept [B,max_out,2] (anchor, class) int32 or NULL,
+ *   gather_payload [B, max_out*6 + 1] or NULL: per image the 6*max_out floats of `proposed` followed
+ *   by the count bit-cast to float -- the fixed-size record one RCCL all-gather merges across GPUs
+ *   (the reference's DP merge is Concatenate(axis=0), engine/parallel.py:92-107).
+ * C <= 64; C*max_out <= 2048 keeps the cross-class stage in LDS, larger values (the constructor
+ * default nms_max_output_size=1000, detection.py:472) run it through the workspace.
  * workspace: >= ml_detection_workspace_bytes(B,A,C,max_out) bytes.                            */
 int64_t ml_detection_workspace_bytes(int32_t B, int32_t A, int32_t C, int32_t max_out);
 int ml_detection_proposal_f32(const float *cls_pred, const float *boxes, float *proposed,
-                              int32_t *counts, int32_t *kept, int32_t B, int32_t A, int32_t C,
+                              int32_t *counts, int32_t *kept, float *gather_payload,
+                              int32_t B, int32_t A, int32_t C,
                               float min_confidence, float nms_iou, float post_iou, int32_t max_out,
                               void *workspace, void *stream);
 
 /* MaskDistribute (engine/layers/instance.py:52-66) + the per-level `tf.where` of
  * PyramidRoiAlign (instance.py:121): proposed [B,cap,6] -> level_slots [B,L,cap] (row indices,
- * ascending), level_counts [B,L].  L = max_k+1.                                                */
+ * ascending), level_counts [B,L], level_max [L] or NULL = max over the images of level_counts
+ * (the second axis MoldBatch gives each level's crops, misc.py:235-236: the one host read of
+ * the forward).  L = max_k+1.                                                                  */
 int ml_mask_distribute_i32(const float *rows, int32_t row_stride, int32_t has_k,
                            float *kvals /* [B,cap] or NULL */, int32_t *level_slots,
-                           int32_t *level_counts, int32_t B, int32_t cap, int32_t max_k,
-                           float base_size, void *stream);
+                           int32_t *level_counts, int32_t *level_max, int32_t B, int32_t cap,
+                           int32_t max_k, float base_size, void *stream);
 /* rows: [B,cap,row_stride]; has_k=0: rows are (cx,cy,w,h,cls,conf) and k is computed
  * (MaskDistribute); has_k=1: rows are dist_boxes (k,cx,cy,w,h,cls,conf) and k is read.        */
 

@@ -35,3 +35,26 @@ __device__ __forceinline__ float ml_apply_act(float v, int act) {
 }
 
 static inline bool ml_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: `done` (one per kernel) remembers
+// in bit d that device d has it.  Host threads that race here both set the same value (idempotent), so an
+// atomic mask is all the synchronisation needed; there is no other mutable state in the library.
+#include <atomic>
+static inline int ml_ensure_dynamic_lds(const void *fn, int bytes, std::atomic<unsigned long long> &done,
+                                        const char *what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        ml_set_error("%s: hipGetDevice failed or device index %d out of range", what, dev);
+        return ML_E_LAUNCH;
+    }
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return ML_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        ml_set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, bytes, hipGetErrorString(e));
+        return ML_E_LAUNCH;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return ML_OK;
+}

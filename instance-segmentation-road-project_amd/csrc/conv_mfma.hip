@@ -3,11 +3,12 @@
 //   M = B*Ho*Wo output pixels, N = output channels, K = taps x span_pad.
 //   A (pixels x K) is gathered straight from the NHWC activation: for one tap the `span`
 //   input channels of a pixel are contiguous, so a K-chunk of 32 floats is one 128-byte line
-//   per output pixel -- no im2col buffer.  Out-of-image taps are zero-filled in registers.
+//   per output pixel -- no im2col buffer.  Out-of-image taps use the buffer out-of-range rule (zeros land in LDS).
 //   B (N x K) is the host-packed weight matrix, k contiguous.
-//   Block = 256 threads = 4 waves; wave tile = TM x TN MFMA tiles of 32x32; K-chunk = 32 floats,
-//   staged global -> registers -> LDS (row stride 36 floats => conflict-free ds_read_b128),
-//   double buffered so the next chunk's global loads fly under the current chunk's 64 MFMAs.
+//   Block = 256 threads = 4 waves; wave tile = TM x TN MFMA tiles of 32x32; K-chunk = 32 floats (128 B per row),
+//   staged with LDS-direct buffer loads (buffer_load_dwordx4 ... lds: no register round trip, no ds_write) into
+//   unpadded 128-byte rows whose 16-byte k-groups are XOR-swizzled (conflict-free ds_read_b128), double buffered
+//   so the next chunk's loads -- issued in pieces between the MFMAs -- fly under the current chunk's 64 MFMAs.
 //   Lane (r = lane&31, h = lane>>5) reads 4 consecutive k per ds_read_b128; MFMA step j pairs
 //   k = 8*ks + j (h=0) with k = 8*ks + 4 + j (h=1) -- A and B use the same pairing, so the sum
 //   over K is unchanged.  Result = a k-ordered fp32 fma chain (exact fp32, no reduced precision).
@@ -26,20 +27,8 @@
 //   slab and a second kernel reduces them in a FIXED order (deterministic, no atomics).
 //   Block -> tile map is XCD aware: the NB column tiles that share one 128-pixel A panel get
 //   ids congruent mod 8, i.e. the same XCD / L2.
-#include <stdlib.h>
 #include "common.h"
 
-#ifdef MASKLAB_STAMPS
-__device__ unsigned long long g_stamps[8 * 64];
-#define STAMP(slot) do { if (stamp_on && it < 64) g_stamps[(slot) * 64 + it] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMP1(idx) do { if ((blockIdx.x == 16) && (threadIdx.x == 0)) g_stamps[7 * 64 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int ml_debug_read_stamps(unsigned long long *host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -1;
-}
-#else
-#define STAMP(slot) do {} while (0)
-#define STAMP1(idx) do {} while (0)
-#endif
 
 namespace {
 
@@ -162,7 +151,6 @@ conv_mfma_kernel(const MultiArgs args) {
     constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
     // (the launcher sizes the dynamic LDS as max(two staging buffers, epilogue tile))
     extern __shared__ __align__(16) float lds[];
-    STAMP1(0);
 
     // ---- which problem / tile / K slice
     int pi = 0;
@@ -182,7 +170,6 @@ conv_mfma_kernel(const MultiArgs args) {
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
-    STAMP1(8);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -204,7 +191,6 @@ conv_mfma_kernel(const MultiArgs args) {
     // so the per-row compares vanish and invalid tail rows rely on their out-of-range base offset.
     const bool nohalo = (p.KH == 1) && (p.KW == 1) && (p.pad_t == 0) && (p.pad_l == 0) && (p.stride == 1) &&
                         (p.cpp_shift == 30) && (p.span % 32 == 0);
-    STAMP1(9);
     // Setup and epilogue run beside the co-resident block's MFMA stream, which leaves them about one VALU
     // issue slot per 64-cycle MFMA (measured: 2 400 cycles for the ~140 instructions below, 9 100 for the
     // ~150 of the store loop) -- so what counts here is the instruction COUNT, not the latency.
@@ -257,7 +243,6 @@ conv_mfma_kernel(const MultiArgs args) {
     const int n = n0 + c4;
     const bool direct = (P.splits == 1);
     const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
-    STAMP1(10);
     f32x4 res[E_ROWS];
     const bool pre_res = direct && p.residual && vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID;
     if (pre_res) {
@@ -292,8 +277,12 @@ conv_mfma_kernel(const MultiArgs args) {
     };
     // Buffer loads: address = resource base + per-lane byte offset (+ scalar offset); any offset >= num_records
     // returns 0, so out-of-image taps need no zero line and no select on the DATA -- one v_cndmask on the offset.
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, (int)P.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, (int)P.wgt_bytes, 0x00020000);
+    // The prefetch of the iteration after the last one is issued all the same (branch-free pieces) but through
+    // resources with num_records = 0: every lane is out of range, nothing is fetched (it used to re-read the last
+    // chunk: +50 % loads on K = 64 convs, +25 % on K = 128).  One s_cselect per chunk.
+    const int in_bytes = (int)P.in_bytes, wgt_bytes = (int)P.wgt_bytes;
+    __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, wgt_bytes, 0x00020000);
     int b_voff[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * 4;
@@ -378,27 +367,19 @@ conv_mfma_kernel(const MultiArgs args) {
     const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8 : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD;
     const int swz = (r >> 1) & 7;                         // f32 math: k-group kg of row r sits in slot kg ^ swz
 
-    STAMP1(1);
     if (kc_begin < kc_end) {
         load_chunk(kc_begin);
         store_chunk(0);
     }
     __syncthreads();
-    STAMP1(2);
 
-#ifdef MASKLAB_STAMPS
-    const bool stamp_on = (blockIdx.x == 16) && (threadIdx.x == 0);
-#endif
     for (int kc = kc_begin; kc < kc_end; ++kc) {
-#ifdef MASKLAB_STAMPS
-        const int it = kc - kc_begin;
-#endif
-        STAMP(0);
         const int buf = (kc - kc_begin) & 1;
         const bool more = kc + 1 < kc_end;
-        // Unconditional prefetch (the last iteration re-reads its own chunk and drops it): no branch.
+        // Unconditional prefetch, no branch: on the last iteration it goes through empty resources (no traffic).
         const int kc_next = more ? kc + 1 : kc;
-        STAMP(1);
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, more ? in_bytes : 0, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, more ? wgt_bytes : 0, 0x00020000);
         const float *base = lds + buf * BUF;
         dst_buf = buf ^ 1;
         piece_begin();
@@ -469,22 +450,14 @@ conv_mfma_kernel(const MultiArgs args) {
                         }
                     }
         }
-        STAMP(2);
-#ifdef MASKLAB_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(5);
-#endif
         if constexpr (F16) {
             if (more) store_chunk(buf ^ 1);
         } else {
             store_chunk(buf ^ 1);        // always: the (dropped) last prefetch must have landed before the epilogue re-uses the LDS
         }
-        STAMP(3);
         __syncthreads();
-        STAMP(4);
     }
 
-    STAMP1(3);
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Transpose the BM x BN tile through LDS (all staging reads finished at the barrier above).
 #pragma unroll
@@ -497,9 +470,7 @@ conv_mfma_kernel(const MultiArgs args) {
                 const int col = wn * TN * 32 + ni * 32 + r;
                 lds[row * C_LD + col] = acc[mi][ni][e];
             }
-    STAMP1(11);
     __syncthreads();
-    STAMP1(12);
 
     if (!direct) {
         // raw partial tile -> slab[slice][m][n] (n_pad pitch); bias/act happen in the reduce kernel
@@ -577,11 +548,6 @@ conv_mfma_kernel(const MultiArgs args) {
             store_out4(p, HoWo, m, n, v, vec_ok, true);
         }
     }
-    STAMP1(4);
-#ifdef MASKLAB_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP1(5);
-#endif
 }
 
 // out = act(sum_s slab[s] + bias + residual), slices summed in index order (deterministic).
@@ -679,20 +645,10 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : 2 * (BM + BN) * LDS_LD * 4;
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
     constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-    static int lds_pad = -1;
-    if (lds_pad < 0) { const char *e = getenv("MASKLAB_CONV_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }   // experiment knob
-    const int LDS_BYTES = LDS_BYTES0 + lds_pad;
+    constexpr int LDS_BYTES = LDS_BYTES0;
     auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, F16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            ml_set_error("conv2d: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
-            return ML_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "conv2d")) return rc;
     MultiArgs args;
     args.n = n;
     long long start = 0, ws_off = 0;

@@ -227,6 +227,24 @@ struct DetWs {
     int *s1_anchor;      // [B*C*max_out]
     u64 *keys;           // [B*C*A]
     f32x4 *cbox;         // [B*C*A]  (y1,x1,y2,x2)
+    // second stage through global memory (only when C*max_out candidates per image do not fit the LDS kernel)
+    int *s2_n;           // [B]           candidates of the image
+    int *s2_count;       // [B]           boxes selected
+    int *s2_sel;         // [B*max_out]   selected candidate positions p
+    int *s2_anchor;      // [B*C*max_out] anchor of candidate p
+    int *s2_class;       // [B*C*max_out] class of candidate p
+    u64 *s2_keys;        // [B*C*max_out]
+    f32x4 *s2_cbox;      // [B*C*max_out]
+};
+
+// what one launch of det_nms_bucket_kernel works on: `count[bucket]` candidates at keys / cbox + bucket * stride
+struct NmsIo {
+    const int *count;
+    u64 *keys;
+    const f32x4 *cbox;
+    int *out_sel;        // [buckets * max_out]  low 32 key bits (inverted) of the selected candidates, in pick order
+    int *out_count;      // [buckets]
+    long long stride;
 };
 
 __host__ __device__ inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -242,6 +260,13 @@ static DetWs det_ws_carve(void *ws, int B, int A, int C, int max_out, long long 
     w.s1_anchor = reinterpret_cast<int *>(p + off); off = align_up(off + BC * max_out * 4, 256);
     w.keys = reinterpret_cast<u64 *>(p + off); off = align_up(off + BC * A * 8, 256);
     w.cbox = reinterpret_cast<f32x4 *>(p + off); off = align_up(off + BC * A * 16, 256);
+    w.s2_n = reinterpret_cast<int *>(p + off); off = align_up(off + (long long)B * 4, 256);
+    w.s2_count = reinterpret_cast<int *>(p + off); off = align_up(off + (long long)B * 4, 256);
+    w.s2_sel = reinterpret_cast<int *>(p + off); off = align_up(off + (long long)B * max_out * 4, 256);
+    w.s2_anchor = reinterpret_cast<int *>(p + off); off = align_up(off + BC * max_out * 4, 256);
+    w.s2_class = reinterpret_cast<int *>(p + off); off = align_up(off + BC * max_out * 4, 256);
+    w.s2_keys = reinterpret_cast<u64 *>(p + off); off = align_up(off + BC * max_out * 8, 256);
+    w.s2_cbox = reinterpret_cast<f32x4 *>(p + off); off = align_up(off + BC * max_out * 16, 256);
     *bytes = off;
     return w;
 }
@@ -328,7 +353,7 @@ struct NmsShared {
 };
 
 __global__ void __launch_bounds__(NMS_T)
-det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf) {
+det_nms_bucket_kernel(NmsIo io, int max_out, float iou_thr, float min_conf) {
     extern __shared__ __align__(16) unsigned char nms_smem[];
     f32x4 *bbox = reinterpret_cast<f32x4 *>(nms_smem);                                   // [NMS_BAND]
     f32x4 *sel = bbox + NMS_BAND;                                                        // [max_out]
@@ -336,9 +361,9 @@ det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf
     unsigned short *bidx = reinterpret_cast<unsigned short *>(bkey + NMS_BAND);          // [NMS_BAND]
     NmsShared *sh = reinterpret_cast<NmsShared *>(bidx + NMS_BAND);
     const int bucket = blockIdx.x;
-    const int n = w.bucket_count[bucket];
-    u64 *keys = w.keys + (long long)bucket * A;
-    const f32x4 *cb = w.cbox + (long long)bucket * A;
+    const int n = io.count[bucket];
+    u64 *keys = io.keys + (long long)bucket * io.stride;
+    const f32x4 *cb = io.cbox + (long long)bucket * io.stride;
     const int tid = threadIdx.x;
 
     // monotone score -> bin map over [min_conf, 1]
@@ -457,7 +482,7 @@ det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf
             bitonic_sort_desc<true>(bkey, bidx, P);
             picked = greedy_sorted<true>(bkey, bidx, bbox, bn, sel, picked, max_out, iou_thr, &sh->greedy,
                                          [&](int slot_out, u64 key, int) {
-                                             w.s1_anchor[(long long)bucket * max_out + slot_out] =
+                                             io.out_sel[(long long)bucket * max_out + slot_out] =
                                                  (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
                                          });
         } else {
@@ -488,7 +513,7 @@ det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf
                 const f32x4 sb = cb[sh->sel_slot];
                 if (tid == 0) {
                     sel[picked] = sb;
-                    w.s1_anchor[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+                    io.out_sel[(long long)bucket * max_out + picked] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
                 }
                 for (int i = tid; i < n; i += NMS_T) {
                     const u64 k = keys[i];
@@ -503,31 +528,16 @@ det_nms_bucket_kernel(DetWs w, int A, int max_out, float iou_thr, float min_conf
         hi = lo;
         band_target = band_target * 4 < NMS_BAND ? band_target * 4 : NMS_BAND;
     }
-    if (tid == 0) w.s1_count[bucket] = picked;
+    if (tid == 0) io.out_count[bucket] = picked;
 }
 
 // 3+4. per-image cross-class NMS (detection.py:531-555) + result rows (:557-563) + -1 padding.
-//      one block per image; candidates (<= C*max_out) live in LDS.
-__global__ void __launch_bounds__(512)
-det_nms_image_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, float *__restrict__ proposed,
-                     int *__restrict__ counts, int *__restrict__ kept, int A, int C, int max_out, float iou_thr) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int order[64];     // bucket ranks (C <= 64)
-    __shared__ int base[65];
-    __shared__ GreedyShared greedy;
-    const int b = blockIdx.x;
-    const int cap2 = C * max_out;
-    int P2 = 64;
-    while (P2 < cap2) P2 <<= 1;
-    f32x4 *cbx = reinterpret_cast<f32x4 *>(smem);                          // [cap2]
-    f32x4 *sel = cbx + cap2;                                               // [max_out]
-    u64 *keys = reinterpret_cast<u64 *>(sel + max_out);                    // [P2]
-    int *anch = reinterpret_cast<int *>(keys + P2);                        // [cap2]
-    int *clsid = anch + cap2;                                              // [cap2]
-    int *pick = clsid + cap2;                                              // [max_out]
 
-    // tf.unique order of the image's (image,class) ids = ascending first-occurrence key
-    __shared__ int bfirst[64], bcount[64];
+// tf.unique order of the image's (image,class) ids = ascending first-occurrence key (detection.py:519-520).
+// order[r] = class of rank r, base[r] = first candidate position of rank r, base[C] = candidates of the image.
+// Called by the whole block; bfirst / bcount are 64-entry scratch arrays.
+__device__ __forceinline__ void image_bucket_order(const DetWs &w, int b, int C, int *order, int *base, int *bfirst,
+                                                   int *bcount) {
     if (threadIdx.x < C) {                                  // one parallel round trip for the bucket headers
         bfirst[threadIdx.x] = w.bucket_first[b * C + threadIdx.x];
         bcount[threadIdx.x] = w.s1_count[b * C + threadIdx.x];
@@ -552,6 +562,65 @@ det_nms_image_kernel(const float *__restrict__ cls, const float *__restrict__ bo
         base[C] = off;
     }
     __syncthreads();
+}
+
+// Result rows (cx,cy,w,h,class,conf) of image b in pick order, -1 padding (MoldBatch, misc.py:276-282), the count,
+// the optional (anchor, class) list, and the optional all-gather payload row
+// [max_out*6 floats of `proposed` | count bit-cast to float] (masklab_hip/parallel.py: ONE collective per batch).
+// ac(r) -> (anchor, class) of pick r.  Called by the whole block.
+template <class AC>
+__device__ __forceinline__ void write_result_rows(const float *__restrict__ cls, const float *__restrict__ boxes,
+                                                  float *__restrict__ proposed, int *__restrict__ counts,
+                                                  int *__restrict__ kept, float *__restrict__ payload, int b, int A, int C,
+                                                  int max_out, int picked, AC ac) {
+    float *pay = payload ? payload + (long long)b * (max_out * 6 + 1) : nullptr;
+    for (int i = threadIdx.x; i < picked * 6; i += blockDim.x) {
+        const int r = i / 6, f = i - r * 6;
+        int a, c;
+        ac(r, a, c);
+        float v;
+        if (f < 4) v = boxes[((long long)b * A + a) * 4 + f];
+        else if (f == 4) v = (float)c;
+        else v = cls[((long long)b * A + a) * C + c];
+        proposed[((long long)b * max_out + r) * 6 + f] = v;
+        if (pay) pay[i] = v;
+        if (kept && f < 2) kept[((long long)b * max_out + r) * 2 + f] = f == 0 ? a : c;
+    }
+    for (int i = picked * 6 + threadIdx.x; i < max_out * 6; i += blockDim.x) {
+        proposed[(long long)b * max_out * 6 + i] = -1.f;
+        if (pay) pay[i] = -1.f;
+    }
+    if (kept)
+        for (int i = picked * 2 + threadIdx.x; i < max_out * 2; i += blockDim.x)
+            kept[(long long)b * max_out * 2 + i] = -1;
+    if (threadIdx.x == 0) {
+        counts[b] = picked;
+        if (pay) pay[max_out * 6] = __int_as_float(picked);
+    }
+}
+
+//      LDS form: one block per image; candidates (<= C*max_out <= 2048) live in LDS.
+__global__ void __launch_bounds__(512)
+det_nms_image_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, float *__restrict__ proposed,
+                     int *__restrict__ counts, int *__restrict__ kept, float *__restrict__ payload, int A, int C,
+                     int max_out, float iou_thr) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int order[64];     // bucket ranks (C <= 64)
+    __shared__ int base[65];
+    __shared__ GreedyShared greedy;
+    __shared__ int bfirst[64], bcount[64];
+    const int b = blockIdx.x;
+    const int cap2 = C * max_out;
+    int P2 = 64;
+    while (P2 < cap2) P2 <<= 1;
+    f32x4 *cbx = reinterpret_cast<f32x4 *>(smem);                          // [cap2]
+    f32x4 *sel = cbx + cap2;                                               // [max_out]
+    u64 *keys = reinterpret_cast<u64 *>(sel + max_out);                    // [P2]
+    int *anch = reinterpret_cast<int *>(keys + P2);                        // [cap2]
+    int *clsid = anch + cap2;                                              // [cap2]
+    int *pick = clsid + cap2;                                              // [max_out]
+
+    image_bucket_order(w, b, C, order, base, bfirst, bcount);
     const int n = base[C];
     for (int p = threadIdx.x; p < n; p += blockDim.x) {      // flat over the image's candidates: one load chain
         int r = 0;
@@ -574,29 +643,52 @@ det_nms_image_kernel(const float *__restrict__ cls, const float *__restrict__ bo
     const int picked = greedy_sorted<false>(
         keys, nullptr, cbx, n, sel, 0, max_out, iou_thr, &greedy, [&](int slot_out, u64, int p) { pick[slot_out] = p; });
     // ... and the result rows (:557-563) are written by the whole block afterwards
-    for (int i = threadIdx.x; i < picked * 6; i += blockDim.x) {
-        const int r = i / 6, f = i - r * 6;
-        const int p = pick[r];
-        const int a = anch[p], c = clsid[p];
-        float v;
-        if (f < 4) v = boxes[((long long)b * A + a) * 4 + f];
-        else if (f == 4) v = (float)c;
-        else v = cls[((long long)b * A + a) * C + c];
-        proposed[((long long)b * max_out + r) * 6 + f] = v;
-        if (kept && f < 2) kept[((long long)b * max_out + r) * 2 + f] = f == 0 ? a : c;
+    write_result_rows(cls, boxes, proposed, counts, kept, payload, b, A, C, max_out, picked,
+                      [&](int r, int &a, int &c) { const int p = pick[r]; a = anch[p]; c = clsid[p]; });
+}
+
+//      Global-memory form for C*max_out > 2048 (e.g. the constructor default nms_max_output_size = 1000,
+//      detection.py:472): (i) the image's stage-1 survivors are laid out as one more bucket -- key = score bits and
+//      the inverted POSITION p in tf.unique order, so ties break like the concatenated per-class list (:541) --,
+//      (ii) det_nms_bucket_kernel runs over these B buckets with post_iou_threshold, (iii) rows are written.
+__global__ void __launch_bounds__(256)
+det_stage2_gather_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, int A, int C, int max_out) {
+    __shared__ int order[64], base[65], bfirst[64], bcount[64];
+    const int b = blockIdx.x;
+    const long long cap2 = (long long)C * max_out;
+    image_bucket_order(w, b, C, order, base, bfirst, bcount);
+    const int n = base[C];
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        int r = 0;
+        while (base[r + 1] <= p) ++r;
+        const int c = order[r];
+        const int a = w.s1_anchor[((long long)b * C + c) * max_out + (p - base[r])];
+        const float s = cls[((long long)b * A + a) * C + c];
+        w.s2_keys[b * cap2 + p] = ((u64)__float_as_uint(s) << 32) | (u64)(0xffffffffu - (unsigned)p);
+        w.s2_cbox[b * cap2 + p] = corners(*reinterpret_cast<const f32x4 *>(boxes + ((long long)b * A + a) * 4));
+        w.s2_anchor[b * cap2 + p] = a;
+        w.s2_class[b * cap2 + p] = c;
     }
-    for (int i = picked * 6 + threadIdx.x; i < max_out * 6; i += blockDim.x)
-        proposed[(long long)b * max_out * 6 + i] = -1.f;
-    if (kept)
-        for (int i = picked * 2 + threadIdx.x; i < max_out * 2; i += blockDim.x)
-            kept[(long long)b * max_out * 2 + i] = -1;
-    if (threadIdx.x == 0) counts[b] = picked;
+    if (threadIdx.x == 0) w.s2_n[b] = n;
+}
+
+__global__ void __launch_bounds__(256)
+det_rows_kernel(const float *__restrict__ cls, const float *__restrict__ boxes, DetWs w, float *__restrict__ proposed,
+                int *__restrict__ counts, int *__restrict__ kept, float *__restrict__ payload, int A, int C, int max_out) {
+    const int b = blockIdx.x;
+    const long long cap2 = (long long)C * max_out;
+    write_result_rows(cls, boxes, proposed, counts, kept, payload, b, A, C, max_out, w.s2_count[b],
+                      [&](int r, int &a, int &c) {
+                          const int p = w.s2_sel[(long long)b * max_out + r];
+                          a = w.s2_anchor[b * cap2 + p];
+                          c = w.s2_class[b * cap2 + p];
+                      });
 }
 
 // ------------------------------------------------------------------ MaskDistribute + level slots
 __global__ void mask_distribute_kernel(const float *__restrict__ rows, int rs, int has_k, float *__restrict__ kvals,
-                                       int *__restrict__ level_slots, int *__restrict__ level_counts, int cap, int max_k,
-                                       float base_size) {
+                                       int *__restrict__ level_slots, int *__restrict__ level_counts,
+                                       int *__restrict__ level_max, int cap, int max_k, float base_size) {
     extern __shared__ int kbuf[];  // [cap]
     const int b = blockIdx.x;
     const int L = max_k + 1;
@@ -626,6 +718,7 @@ __global__ void mask_distribute_kernel(const float *__restrict__ rows, int rs, i
         for (int i = 0; i < cap; ++i)
             if (kbuf[i] == lvl) level_slots[((long long)b * L + lvl) * cap + n++] = i;
         level_counts[b * L + lvl] = n;
+        if (level_max) atomicMax(&level_max[lvl], n);    // MoldBatch's per-level second axis (misc.py:235-236); zeroed by the launcher
         for (int i = n; i < cap; ++i) level_slots[((long long)b * L + lvl) * cap + i] = -1;
     }
 }
@@ -703,17 +796,16 @@ extern "C" int64_t ml_detection_workspace_bytes(int32_t B, int32_t A, int32_t C,
 }
 
 extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *boxes, float *proposed, int32_t *counts,
-                                         int32_t *kept, int32_t B, int32_t A, int32_t C, float min_confidence,
-                                         float nms_iou, float post_iou, int32_t max_out, void *workspace,
-                                         void *stream) {
+                                         int32_t *kept, float *gather_payload, int32_t B, int32_t A, int32_t C,
+                                         float min_confidence, float nms_iou, float post_iou, int32_t max_out,
+                                         void *workspace, void *stream) {
     ML_REQUIRE(cls_pred && boxes && proposed && counts && workspace, "detection_proposal: null pointer");
     ML_REQUIRE(B > 0 && A > 0 && C > 0 && C <= 64 && max_out > 0, "detection_proposal: bad dims (C <= 64)");
     ML_REQUIRE((long long)A * C < (1ll << 31), "detection_proposal: A*C overflows the first-occurrence key");
+    ML_REQUIRE((long long)B * C * max_out < (1ll << 31), "detection_proposal: B*C*max_out overflows int32");
     ML_REQUIRE(ml_aligned16(boxes) && (((uintptr_t)workspace) & 255) == 0, "detection_proposal: alignment");
-    ML_REQUIRE(C * max_out <= 2048, "detection_proposal: C*max_out = %d exceeds the stage-2 LDS capacity 2048", C * max_out);
-    long long p2 = 64;
-    while (p2 < (long long)C * max_out) p2 <<= 1;
-    const long long lds2 = (long long)C * max_out * 24 + (long long)max_out * 20 + p2 * 8;
+    const size_t nms_lds = (size_t)NMS_BAND * 16 + (size_t)max_out * 16 + (size_t)NMS_BAND * 10 + sizeof(NmsShared);
+    ML_REQUIRE(nms_lds <= 160 * 1024, "detection_proposal: max_out %d too large for the NMS LDS budget", max_out);
     long long bytes = 0;
     DetWs w = det_ws_carve(workspace, B, A, C, max_out, &bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -722,35 +814,41 @@ extern "C" int ml_detection_proposal_f32(const float *cls_pred, const float *box
     const long long per_image = (long long)A * C;
     hipLaunchKernelGGL(det_threshold_kernel, dim3((unsigned)((per_image + DET_EPB - 1) / DET_EPB), B), dim3(256), 0, s,
                        cls_pred, boxes, w, A, C, min_confidence);
-    {
-        const size_t nms_lds = (size_t)NMS_BAND * 16 + (size_t)max_out * 16 + (size_t)NMS_BAND * 10 + sizeof(NmsShared);
-        ML_REQUIRE(nms_lds <= 160 * 1024, "detection_proposal: max_out %d too large for the NMS LDS budget", max_out);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_bucket_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) {
-                ml_set_error("detection_proposal: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                return ML_E_LAUNCH;
-            }
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(NMS_T), nms_lds, s, w, A, max_out, nms_iou, min_confidence);
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(det_nms_bucket_kernel), 160 * 1024, lds_ok,
+                                       "detection_proposal"))
+        return rc;
+    const NmsIo io1 = {w.bucket_count, w.keys, w.cbox, w.s1_anchor, w.s1_count, (long long)A};
+    hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(BC), dim3(NMS_T), nms_lds, s, io1, max_out, nms_iou, min_confidence);
+    if (C * max_out <= 2048) {
+        long long p2 = 64;
+        while (p2 < (long long)C * max_out) p2 <<= 1;
+        const long long lds2 = (long long)C * max_out * 24 + (long long)max_out * 20 + p2 * 8;
+        hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(512), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
+                           kept, gather_payload, A, C, max_out, post_iou);
+    } else {
+        hipLaunchKernelGGL(det_stage2_gather_kernel, dim3(B), dim3(256), 0, s, cls_pred, boxes, w, A, C, max_out);
+        const NmsIo io2 = {w.s2_n, w.s2_keys, w.s2_cbox, w.s2_sel, w.s2_count, (long long)C * max_out};
+        hipLaunchKernelGGL(det_nms_bucket_kernel, dim3(B), dim3(NMS_T), nms_lds, s, io2, max_out, post_iou, min_confidence);
+        hipLaunchKernelGGL(det_rows_kernel, dim3(B), dim3(256), 0, s, cls_pred, boxes, w, proposed, counts, kept,
+                           gather_payload, A, C, max_out);
     }
-    hipLaunchKernelGGL(det_nms_image_kernel, dim3(B), dim3(512), (size_t)lds2, s, cls_pred, boxes, w, proposed, counts,
-                       kept, A, C, max_out, post_iou);
     ML_CHECK_LAUNCH("detection_proposal");
     return ML_OK;
 }
 
 extern "C" int ml_mask_distribute_i32(const float *rows, int32_t row_stride, int32_t has_k, float *kvals,
-                                      int32_t *level_slots, int32_t *level_counts, int32_t B, int32_t cap,
-                                      int32_t max_k, float base_size, void *stream) {
+                                      int32_t *level_slots, int32_t *level_counts, int32_t *level_max, int32_t B,
+                                      int32_t cap, int32_t max_k, float base_size, void *stream) {
     ML_REQUIRE(rows && level_slots && level_counts && B > 0 && cap > 0, "mask_distribute: bad arguments");
     ML_REQUIRE(row_stride >= (has_k ? 5 : 4), "mask_distribute: row_stride too small");
     ML_REQUIRE(max_k >= 0 && max_k < 64, "mask_distribute: max_k out of range");
+    if (level_max && hipMemsetAsync(level_max, 0, (size_t)(max_k + 1) * 4, (hipStream_t)stream) != hipSuccess) {
+        ml_set_error("mask_distribute: hipMemsetAsync failed");
+        return ML_E_LAUNCH;
+    }
     hipLaunchKernelGGL(mask_distribute_kernel, dim3(B), dim3(128), (size_t)cap * 4, (hipStream_t)stream, rows, row_stride,
-                       has_k, kvals, level_slots, level_counts, cap, max_k, base_size);
+                       has_k, kvals, level_slots, level_counts, level_max, cap, max_k, base_size);
     ML_CHECK_LAUNCH("mask_distribute");
     return ML_OK;
 }

@@ -228,16 +228,8 @@ int launch16(const float *in, const float *wgt, const float *bias, float *out, i
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
     constexpr int LDS_BYTES = THIN * TWIN * PS16 * 4;
     auto kern = gconv16_kernel<STRIDE, TH, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            ml_set_error("gconv3x3: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
-            return ML_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho,
                        Wo, pad_t, pad_l, act, tiles_x);
@@ -251,16 +243,8 @@ int launch(const float *in, const float *wgt, const float *bias, float *out, int
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
     constexpr int LDS_BYTES = THIN * TWIN * PS * 4;
     auto kern = gconv_mfma4_kernel<STRIDE, TH, TW, CPG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) {
-            ml_set_error("gconv3x3: hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
-            return ML_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C,
                        Ho, Wo, pad_t, pad_l, act, tiles_x);

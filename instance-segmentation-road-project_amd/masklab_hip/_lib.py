@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
 LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
 
-ABI_VERSION = 2          # ML_ABI_VERSION of include/masklab_hip.h
+ABI_VERSION = 3          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -59,8 +59,8 @@ SIGNATURES = {
     "ml_scale_channels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "ml_restore_boxes_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "ml_detection_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
-    "ml_detection_proposal_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp]),
-    "ml_mask_distribute_i32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ml_detection_proposal_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "ml_mask_distribute_i32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ml_roi_crop_resize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp]),
     "ml_add_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_fill_f32": (C.c_int, [_vp, _f32, _i64, _vp]),

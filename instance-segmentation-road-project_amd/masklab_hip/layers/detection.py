@@ -274,19 +274,20 @@ class DetectionProposal(Layer):
         self.max_batch_size = max_batch_size
         super().__init__(**kwargs)
 
-    def propose_fixed(self, cls_pred, boxes, want_kept=False):
-        """-> proposed [B,cap,6] (-1 padded), counts [B] int32 (device), kept [B,cap,2] or None."""
+    def propose_fixed(self, cls_pred, boxes, want_kept=False, want_payload=False):
+        """-> proposed [B,cap,6] (-1 padded), counts [B] int32 (device), kept [B,cap,2] or None
+        [, payload [B,cap*6+1]: the all-gather record, see parallel.all_gather_detections]."""
         if cls_pred.shape[0] > 32 and self.max_batch_size is not None:
             raise ValueError("DetectionProposal: MoldBatch supports at most 32 images per call "
                              "(reference misc.py:275); shard larger batches")
         return ops.detection_proposal(cls_pred.contiguous(), boxes.contiguous(), self.min_confidence,
                                       self.nms_iou_threshold, self.post_iou_threshold,
-                                      self.nms_max_output_size, want_kept=want_kept)
+                                      self.nms_max_output_size, want_kept=want_kept, want_payload=want_payload)
 
     def call(self, inputs, **kwargs):
         cls_pred, boxes = inputs[0], inputs[1]
         proposed, counts, _ = self.propose_fixed(cls_pred, boxes)
-        n = max(1, int(counts.max().item()))
+        n = max(1, max(counts.tolist()))          # the dynamic N of the reference (MoldBatch): B ints read by the host
         return proposed[:, :n].contiguous()
 
     def get_config(self):

@@ -18,7 +18,9 @@ class MaskDistribute(Layer):
 
     def call(self, inputs, **kwargs):
         inputs = inputs.contiguous()
-        _, _, kvals = ops.mask_distribute(inputs, self.max_k, self.base_size, has_k=False, want_k=True)
+        _, _, _, kvals = ops.mask_distribute(inputs, self.max_k, self.base_size, has_k=False, want_k=True)
+        # Concatenate([k, boxes], axis=-1) (:66): data movement of a [B,N,7] table, off the fused hot path
+        # (InferenceModel consumes the level slots directly and never builds dist_boxes)
         return torch.cat([kvals[..., None], inputs], dim=-1)
 
     def get_config(self):
@@ -41,14 +43,15 @@ class PyramidRoiAlign(Layer):
         """Enqueue the level assignment + per-level slot lists (no host read)."""
         if rows.shape[0] > 32 and self.max_batch_size is not None:
             raise ValueError("PyramidRoiAlign: MoldBatch supports at most 32 images per call")
-        slots, lcounts, _ = ops.mask_distribute(rows, n_levels - 1, base_size, has_k=has_k)
-        return slots, lcounts
+        slots, lcounts, lmax, _ = ops.mask_distribute(rows, n_levels - 1, base_size, has_k=has_k)
+        return slots, lcounts, lmax
 
-    def crop_distributed(self, fmap_outputs, rows, image_hw, slots, lcounts):
-        """One device->host read (per-level counts) sizes the molded outputs like the reference's dynamic
-        shapes; callers enqueue independent work (the semantic head) before calling this."""
+    def crop_distributed(self, fmap_outputs, rows, image_hw, slots, lcounts, lmax):
+        """One device->host read (`lmax`: the per-level maxima the distribute kernel wrote, L ints) sizes the
+        molded outputs like the reference's dynamic shapes; callers enqueue independent work (the semantic
+        head) before calling this."""
         B = rows.shape[0]
-        n_l = [max(1, int(v)) for v in lcounts.max(dim=0).values.tolist()]     # the single sync
+        n_l = [max(1, int(v)) for v in lmax.tolist()]     # the single sync
         total = sum(n_l)
         roi_boxes = torch.empty((B, total, 6), dtype=torch.float32, device=rows.device)
         roi_fmaps, off = [], 0
@@ -60,8 +63,8 @@ class PyramidRoiAlign(Layer):
 
     def crop_levels(self, fmap_outputs, rows, image_hw, has_k, base_size=1.0):
         """rows: [B,cap,6] proposals (has_k=False) or [B,cap,7] dist_boxes (has_k=True)."""
-        slots, lcounts = self.distribute(len(fmap_outputs), rows, has_k, base_size)
-        return self.crop_distributed(fmap_outputs, rows, image_hw, slots, lcounts)
+        slots, lcounts, lmax = self.distribute(len(fmap_outputs), rows, has_k, base_size)
+        return self.crop_distributed(fmap_outputs, rows, image_hw, slots, lcounts, lmax)
 
     def call(self, inputs, **kwargs):
         fmap_outputs, dist_boxes, images = inputs[0], inputs[1], inputs[2]
@@ -126,10 +129,25 @@ class MaskSubNet(Layer, _TowerMixin):
         xs = self._run_towers_multi([b[:-2] for b in blocks], xs)
         xs = ops.conv2d_multi([dict(x=x, dc=b[-2].dev, act=_lib.ACT_BY_NAME[b[-2].activation])
                                for b, x in zip(blocks, xs)])                    # Conv2DTranspose + ReLU
-        xs = ops.conv2d_multi([dict(x=x, dc=b[-1].dev, stride=1, padding=b[-1].padding,
-                                    act=_lib.ACT_BY_NAME[b[-1].activation]) for b, x in zip(blocks, xs)])
-        heads = [x.reshape((B, n) + tuple(x.shape[1:])) for (B, n), x in zip(shapes, xs)]
-        return torch.cat(heads, dim=1) if len(heads) > 1 else heads[0]   # Concatenate(axis=1): data movement
+        # unfold + Concatenate(axis=1) (:222-225) fused into the output convs: level l's [B*n_l, h, w, classes] maps
+        # land at rows [off_l, off_l + n_l) of every image of roi_masks through a per-image strided view.  The
+        # view's "image" is one RoI-level block: problem (b, level) would need B problems per level, so instead the
+        # conv's batch axis is the IMAGE (n_l RoIs of one image are n_l*h rows of a [B, n_l*h, w, classes] map).
+        B = shapes[0][0]
+        oh, ow = int(xs[0].shape[1]), int(xs[0].shape[2])
+        ncls = self.num_classes
+        total = sum(n for _, n in shapes)
+        roi_masks = torch.empty((B, total, oh, ow, ncls), dtype=torch.float32, device=xs[0].device)
+        per_roi = oh * ow * ncls
+        problems, off = [], 0
+        for (_, n), b, x in zip(shapes, blocks, xs):
+            xv = x.reshape(B, n * oh, ow, x.shape[3])          # a view: RoIs of one image stacked along H (1x1 conv)
+            problems.append(dict(x=xv, dc=b[-1].dev, stride=1, padding=b[-1].padding,
+                                 act=_lib.ACT_BY_NAME[b[-1].activation],
+                                 out_view=(roi_masks, off * per_roi, ncls, total * per_roi)))
+            off += n
+        ops.conv2d_multi(problems)
+        return roi_masks
 
     def get_config(self):
         config = super().get_config()

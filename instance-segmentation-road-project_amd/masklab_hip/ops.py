@@ -54,6 +54,11 @@ def set_conv_math(mode):
     CONV_MATH = mode
 
 
+def dtype_label():
+    """The arithmetic type the dense-conv path computes in (bench.py's `dtype`)."""
+    return {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate, f32 tensors"}[CONV_MATH]
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -326,9 +331,11 @@ def restore_boxes(loc_pred, priors_i32):
     return boxes
 
 
-def detection_proposal(cls_pred, boxes, min_confidence, nms_iou, post_iou, max_out, want_kept=False):
+def detection_proposal(cls_pred, boxes, min_confidence, nms_iou, post_iou, max_out, want_kept=False,
+                       want_payload=False):
     """Fixed-capacity DetectionProposal: -> proposed [B,max_out,6] (-1 padded), counts [B] int32
-    (device), kept [B,max_out,2] int32 or None."""
+    (device), kept [B,max_out,2] int32 or None[, payload [B,max_out*6+1] -- the all-gather record the
+    kernel writes beside `proposed`, see parallel.all_gather_detections]."""
     lib = _lib.load()
     _require_dev(cls_pred, "cls_pred")
     _require_dev(boxes, "boxes")
@@ -337,27 +344,33 @@ def detection_proposal(cls_pred, boxes, min_confidence, nms_iou, post_iou, max_o
     proposed = torch.empty((B, max_out, 6), dtype=torch.float32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     kept = torch.empty((B, max_out, 2), dtype=torch.int32, device=dev) if want_kept else None
+    payload = torch.empty((B, max_out * 6 + 1), dtype=torch.float32, device=dev) if want_payload else None
     ws = workspace(lib.ml_detection_workspace_bytes(B, A, Cn, max_out), dev, "det")
     with _Prof("detection_proposal", 0, 4 * (cls_pred.numel() + boxes.numel())):
         _lib.check(lib.ml_detection_proposal_f32(_ptr(cls_pred), _ptr(boxes), _ptr(proposed), _ptr(counts), _ptr(kept),
-                                                 B, A, Cn, float(min_confidence), float(nms_iou), float(post_iou),
-                                                 int(max_out), _ptr(ws), _stream()), "ml_detection_proposal_f32")
+                                                 _ptr(payload), B, A, Cn, float(min_confidence), float(nms_iou),
+                                                 float(post_iou), int(max_out), _ptr(ws), _stream()),
+                   "ml_detection_proposal_f32")
+    if want_payload:
+        return proposed, counts, kept, payload
     return proposed, counts, kept
 
 
 def mask_distribute(rows, max_k, base_size, has_k=False, want_k=False):
     """rows [B,cap,6] (has_k=False: k computed per MaskDistribute) or [B,cap,7] dist_boxes
-    (has_k=True).  -> level_slots [B,L,cap] int32, level_counts [B,L] int32, kvals [B,cap] or None."""
+    (has_k=True).  -> level_slots [B,L,cap] int32, level_counts [B,L] int32, level_max [L] int32 (max over
+    the images: the one thing the host reads), kvals [B,cap] or None."""
     lib = _lib.load()
     _require_dev(rows, "rows")
     B, cap, rs = rows.shape
     L = max_k + 1
     slots = torch.empty((B, L, cap), dtype=torch.int32, device=rows.device)
     lcounts = torch.empty((B, L), dtype=torch.int32, device=rows.device)
+    lmax = torch.empty((L,), dtype=torch.int32, device=rows.device)
     kvals = torch.empty((B, cap), dtype=torch.float32, device=rows.device) if want_k else None
-    _lib.check(lib.ml_mask_distribute_i32(_ptr(rows), rs, int(has_k), _ptr(kvals), _ptr(slots), _ptr(lcounts), B, cap,
-                                          max_k, float(base_size), _stream()), "ml_mask_distribute_i32")
-    return slots, lcounts, kvals
+    _lib.check(lib.ml_mask_distribute_i32(_ptr(rows), rs, int(has_k), _ptr(kvals), _ptr(slots), _ptr(lcounts), _ptr(lmax),
+                                          B, cap, max_k, float(base_size), _stream()), "ml_mask_distribute_i32")
+    return slots, lcounts, lmax, kvals
 
 
 def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, roi_boxes, box_off):

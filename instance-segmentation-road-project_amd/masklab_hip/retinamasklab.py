@@ -192,6 +192,14 @@ class InferenceModel(K.Layer):
             l.load_weights(weights, self.device)
         return self
 
+    def reload_class_outputs(self, weights):
+        """Re-pack and upload only the class towers' output convs (parity fixtures rescale those kernels to
+        move the score distribution; everything else keeps its device copy)."""
+        if self.detection_networks is None:
+            raise RuntimeError("no detection networks")
+        for block in self.detection_networks[2].blocks:
+            block[-1].load_weights(weights, self.device)
+
     # ---- forward (reference :431-491)
     # Stage 1 = everything up to the one host read (backbone, FPN, towers, box decode, DetectionProposal,
     # level assignment, semantic head); stage 2 = RoI crops + mask head, whose molded shapes depend on the
@@ -244,15 +252,15 @@ class InferenceModel(K.Layer):
                 restored_boxes = restore_subnet([st["loc_pred"], pr_boxes])
                 # fused DetectionProposal -> MaskDistribute -> PyramidRoiAlign in fixed capacity:
                 # the only host read is the per-level RoI count that sizes the molded outputs.
-                proposed, counts, kept = self.detection_proposal.propose_fixed(
-                    st["cls_pred"], restored_boxes, want_kept=want_kept)
+                proposed, counts, kept, payload = self.detection_proposal.propose_fixed(
+                    st["cls_pred"], restored_boxes, want_kept=want_kept, want_payload=True)
                 n_levels = cfg.instance.max_k + 1
                 if distribute_subnet.max_k + 1 != n_levels:
                     raise ValueError("MaskDistribute.max_k does not match config.instance.max_k")
-                slots, lcounts = pyramid_roi_align.distribute(n_levels, proposed, has_k=False,
-                                                              base_size=distribute_subnet.base_size)
-                st.update(proposed=proposed, counts=counts, kept=kept, boxes=restored_boxes, slots=slots,
-                          lcounts=lcounts, roi_features=feature_outputs[:n_levels])
+                slots, lcounts, lmax = pyramid_roi_align.distribute(n_levels, proposed, has_k=False,
+                                                                    base_size=distribute_subnet.base_size)
+                st.update(proposed=proposed, counts=counts, kept=kept, payload=payload, boxes=restored_boxes,
+                          slots=slots, lcounts=lcounts, lmax=lmax, roi_features=feature_outputs[:n_levels])
         if side is not None:
             st["side"] = side
             st["keepalive"] = by_name            # backbone taps the side stream still reads
@@ -278,11 +286,11 @@ class InferenceModel(K.Layer):
             if self.instance_networks is not None:
                 _, _, pyramid_roi_align, mask_subnet = self.instance_networks
                 roi_fmaps, roi_boxes = pyramid_roi_align.crop_distributed(
-                    st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"])
+                    st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"], st["lmax"])
                 roi_masks = mask_subnet(roi_fmaps)
                 outputs += [roi_boxes, roi_masks]
                 self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"],
-                                            boxes=st["boxes"])
+                                            boxes=st["boxes"], payload=st["payload"])
         self._join_side(st)
         if self.semantic_networks is not None:
             outputs.append(st["seg_pred"])

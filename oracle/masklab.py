@@ -475,9 +475,11 @@ def segmentation_subnet(aspp_out, skip, w, depth, groups, use_se=False, use_sep=
 # =========================================================================== whole path
 def inference_forward(config, weights, images, dtype=np.float32, literal_groups=True,
                       with_detection=True, with_instance=True, with_semantic=True,
-                      return_internals=False):
+                      return_internals=False, min_confidence=None):
     """construct_inference_network, engine/retinamasklab.py:420-495.
-    Returns [cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred] (subset by flags)."""
+    Returns [cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred] (subset by flags).
+    min_confidence: None = config.detection.min_confidence (:459-466); a float overrides it; a callable
+    cls_pred -> float chooses it from the scores (fixtures put it in a score gap), reported in internals."""
     w = weights
     x = np.asarray(images).astype(dtype)
     B, H, W, _ = x.shape
@@ -504,8 +506,11 @@ def inference_forward(config, weights, images, dtype=np.float32, literal_groups=
         if with_instance:
             ins = config.instance
             boxes = restore_boxes(loc_pred, pr[None])                                   # :458
+            thr = det.min_confidence if min_confidence is None else (
+                min_confidence(cls_pred) if callable(min_confidence) else min_confidence)
+            internals["min_confidence"] = float(thr)
             proposed, kept = detection_proposal(
-                cls_pred, boxes, det.min_confidence, det.nms_iou_threshold,
+                cls_pred, boxes, thr, det.nms_iou_threshold,
                 det.post_iou_threshold, det.nms_max_output_size,
                 config.train.inference_batch_size)                                      # :459-466
             dist = mask_distribute(proposed, ins.max_k, ins.base_size)                  # :467

@@ -32,7 +32,7 @@ def test_bench_json_contract_single_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "resnext50_full_b2_256",
-                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -47,7 +47,46 @@ def test_bench_json_contract_single_rank():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
     assert d["cpu_baseline"]["kind"] == "port"
+    for key in ("cpu_model", "blas_threads", "images_per_sec"):
+        assert key in d["cpu_baseline"], key
+    assert any("1 thread" in k for k in d["cpu_baseline"]["images_per_sec"])
     assert d["parity"]["ok"] is True and d["parity"]["detection_fmeasure"] > 0.999
+    assert d["parity"]["rows_exact"] is True and d["parity"]["order_exact"] is True
+    assert all("hbm_frac" in v or "mfma_frac" in v for k, v in d["kernels"].items()
+               if k.startswith(("conv_mfma", "groupnorm", "gconv3x3")))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 8` started bare on a box with fewer GPUs must fail, not measure one GPU and say so
+    in small print.  The check runs before the process touches the device."""
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASKLAB_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher-provided WORLD_SIZE that disagrees with --gpus is refused too
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                       capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_bare_gpus2_spawns_its_own_ranks():
+    """bare `--gpus 2` launches two ranks itself (rehearsal mode: both on cuda:0 over gloo) and relays ONE JSON line."""
+    env = dict(os.environ, MASKLAB_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                        "resnext50_full_b2_256", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
+    assert "merged batch 4" in d["config"]["collective"]
 
 
 def test_bench_two_ranks_rehearsal():
@@ -60,3 +99,4 @@ def test_bench_two_ranks_rehearsal():
     d = _json_line(r.stdout)                       # exactly one line: rank 0 reports
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    assert "merged batch 4" in d["config"]["collective"]            # the gather really merged both ranks' images

@@ -142,6 +142,38 @@ def test_detection_proposal_tie_break_lower_index():
     np.testing.assert_array_equal(host(prop)[:, :ref.shape[1]], ref)
 
 
+@pytest.mark.parametrize("B,hw,frac", [(2, (128, 128), 0.01), (1, (256, 256), 0.05), (3, (128, 128), 0.3)])
+def test_detection_proposal_keras_default_max_output_1000(B, hw, frac):
+    """nms_max_output_size=1000 is the DetectionProposal constructor default (reference detection.py:472):
+    C*max_out = 5000 candidates per image do not fit the LDS cross-class stage, so it runs through the
+    workspace (gather -> banded bucket NMS -> rows).  Same bit-exact bar; up to 1000 rows come out."""
+    from masklab_hip import ops
+    pri, cls, loc = _synthetic_head(B, hw[0], hw[1], frac=frac, seed=10 + B)
+    boxes = O.restore_boxes(loc, pri[None])
+    ref, kept_ref = O.detection_proposal(cls, boxes, 0.5, 0.4, 0.6, 1000)
+    prop, counts, kept = ops.detection_proposal(dev(cls), dev(boxes), 0.5, 0.4, 0.6, 1000, want_kept=True)
+    prop, counts, kept = host(prop), host(counts), host(kept)
+    n = max(1, int(counts.max()))
+    assert ref.shape == (B, n, 6) and (frac < 0.05 or n > 100)     # the dense case really exceeds the old cap
+    np.testing.assert_array_equal(prop[:, :n], ref)
+    assert np.all(prop[:, n:] == -1)
+    for b in range(B):
+        np.testing.assert_array_equal(kept[b, :counts[b]], kept_ref[kept_ref[:, 0] == b][:, 1:])
+
+
+def test_detection_gather_payload_is_proposed_plus_count():
+    """gather_payload (the all-gather record): per image the 600 floats of `proposed` and the count bit-cast."""
+    from masklab_hip import ops, parallel
+    pri, cls, loc = _synthetic_head(3, 128, 128, frac=0.01, seed=4)
+    boxes = O.restore_boxes(loc, pri[None])
+    prop, counts, _, payload = ops.detection_proposal(dev(cls), dev(boxes), 0.5, 0.4, 0.6, 100, want_payload=True)
+    p2, c2 = parallel.unpack_payload(payload, 100)
+    torch.cuda.synchronize()
+    assert payload.shape == (3, 601)
+    assert torch.equal(p2, prop) and torch.equal(c2, counts)
+    assert p2.data_ptr() == payload.data_ptr()                     # views, not copies
+
+
 def test_mask_distribute_and_roi_crop():
     from masklab_hip import ops
     from masklab_hip.layers import MaskDistribute, PyramidRoiAlign
@@ -167,6 +199,10 @@ def test_mask_distribute_and_roi_crop():
         np.testing.assert_array_equal(g == -1.0, r == -1.0)        # MoldBatch padding pattern
         np.testing.assert_allclose(g, r, atol=2e-5)
         np.testing.assert_array_equal(g == 0.0, r == 0.0)          # extrapolation cells (in_y<0 etc.)
+    # the per-level maxima the kernel reports (the host's one read) = max over images of the level counts
+    slots, lcounts, lmax, _ = ops.mask_distribute(dev(prop), 2, 36.0)
+    np.testing.assert_array_equal(host(lmax), host(lcounts).max(axis=0))
+    np.testing.assert_array_equal(host(lcounts).sum(axis=1), n_real)
     # fused path used by the model: k computed inside from the [B,cap,6] proposals
     rf2, rb2 = PyramidRoiAlign((14, 14)).crop_levels([dev(f) for f in fmaps], dev(prop), (H, W), has_k=False,
                                                       base_size=36)

@@ -425,3 +425,147 @@ def test_road_regression_matches_float64_least_squares():
     y = np.arange(H)
     want = 3.25 / np.clip((y * rt[0] + rt[1]) - (y * lt[0] + lt[1]), 1, np.inf)
     np.testing.assert_allclose(unit, want, rtol=2e-3)
+
+
+# ------------------------------------------------------------------ independent implementations
+# The oracle cannot be pinned to TensorFlow here (no TF, no reference fixtures), so every restated op is
+# also checked against an implementation that shares NO code with oracle/: torch-CPU library kernels and a second,
+# loop-form DetectionProposal written straight from the reference text.
+@pytest.mark.parametrize("shape,out", [((2, 5, 7, 4), (11, 13)), ((1, 32, 32, 8), (128, 128)), ((1, 1, 1, 6), (9, 4)),
+                                       ((2, 9, 6, 3), (9, 6)), ((1, 16, 16, 4), (5, 3))])
+def test_resize_bilinear_vs_torch_interpolate_align_corners(shape, out):
+    x = rnd(*shape)
+    ref = F.interpolate(_nchw(x.astype(np.float64)), size=out, mode="bilinear", align_corners=True)
+    # the oracle computes the source coordinate o*(in-1)/(out-1) in fp32 like TF's kernel does: a position error of
+    # <= 1 ulp(in) ~ 1e-5 moves a value by <= 1e-5 * |neighbour difference|
+    np.testing.assert_allclose(T.resize_bilinear_align_corners(x, *out), ref.numpy().transpose(0, 2, 3, 1), atol=4e-5)
+
+
+@pytest.mark.parametrize("shape,G", [((2, 4, 4, 32), 16), ((1, 14, 14, 128), 16), ((3, 8, 8, 128), 32), ((1, 6, 5, 12), 3)])
+def test_group_norm_vs_torch_group_norm_on_the_5d_view(shape, G):
+    """normalization.py:123-143 reshapes NHWC row-major to [N,G,H,W,C/G] and normalises over the last three axes:
+    on that 5-D view it is torch's group_norm with G 'channels groups' of one channel each; gamma / beta are
+    broadcast as [1,G,1,1,C/G] (:151-156)."""
+    x = rnd(*shape)
+    N, H, W, C = shape
+    gamma, beta = RNG.uniform(0.5, 1.5, C).astype(np.float32), rnd(C)
+    v = torch.from_numpy(x.astype(np.float64)).reshape(N, G, H * W * C // G)          # [N, G channels, L]
+    y = F.group_norm(v, G, eps=1e-5).reshape(N, G, H, W, C // G)
+    y = y * torch.from_numpy(gamma.astype(np.float64)).reshape(1, G, 1, 1, C // G) + \
+        torch.from_numpy(beta.astype(np.float64)).reshape(1, G, 1, 1, C // G)
+    np.testing.assert_allclose(T.group_norm(x.astype(np.float64), gamma, beta, G), y.reshape(N, H, W, C).numpy(),
+                               atol=1e-9)
+
+
+@pytest.mark.parametrize("stride,c,groups", [(1, 4, 32), (2, 4, 32), (1, 8, 32), (2, 16, 32)])
+def test_grouped_conv_vs_torch_conv2d_groups(stride, c, groups):
+    """DepthwiseConv2D(depth_multiplier=c) + reshape + reduce_sum (ResNext.py:212-219) IS a grouped
+    convolution with Wg[kh,kw,i,g*c+m] = K[kh,kw,g*c+i,m]; checked against torch's own grouped conv."""
+    filters = groups * c
+    x, k = rnd(2, 9, 10, filters), rnd(3, 3, filters, c)
+    lit = O.grouped_conv_literal(x.astype(np.float64), k.astype(np.float64), groups, c, stride)
+    # torch weight [out, in/groups, kh, kw]: out channel g*c+m, in-group channel i  <-  K[:, :, g*c+i, m]
+    wt = np.zeros((filters, c, 3, 3))
+    for g in range(groups):
+        for m in range(c):
+            for i in range(c):
+                wt[g * c + m, i] = k[:, :, g * c + i, m]
+    ref = F.conv2d(_nchw(x.astype(np.float64)), torch.from_numpy(wt), stride=stride, padding=1, groups=groups)
+    np.testing.assert_allclose(lit, ref.numpy().transpose(0, 2, 3, 1), atol=1e-10)
+    np.testing.assert_allclose(O.grouped_conv_fast(x.astype(np.float64), k, groups, c, stride), lit, atol=1e-10)
+
+
+def _detection_proposal_loops(cls_pred, boxes, min_conf, nms_iou, post_iou, max_out):
+    """Second restatement of DetectionProposal.call, written line by line from reference detection.py:482-567 with
+    plain Python loops and its own IoU / greedy NMS (shares nothing with oracle.masklab.detection_proposal or
+    oracle.tfops.non_max_suppression)."""
+    f32 = np.float32
+
+    def iou(a, b):                                           # tf non_max_suppression: y1,x1,y2,x2, area<=0 -> 0
+        ay1, ax1, ay2, ax2 = min(a[0], a[2]), min(a[1], a[3]), max(a[0], a[2]), max(a[1], a[3])
+        by1, bx1, by2, bx2 = min(b[0], b[2]), min(b[1], b[3]), max(b[0], b[2]), max(b[1], b[3])
+        aa, ab = f32(ay2 - ay1) * f32(ax2 - ax1), f32(by2 - by1) * f32(bx2 - bx1)
+        if aa <= 0 or ab <= 0:
+            return f32(0)
+        ih = max(f32(min(ay2, by2) - max(ay1, by1)), f32(0))
+        iw = max(f32(min(ax2, bx2) - max(ax1, bx1)), f32(0))
+        inter = f32(ih * iw)
+        return f32(inter / f32(f32(aa + ab) - inter))
+
+    def nms(cands, thr):                                     # cands: list of (score, tie index, corner box, payload)
+        order = sorted(range(len(cands)), key=lambda i: (-cands[i][0], cands[i][1]))
+        keep = []
+        for i in order:
+            if len(keep) >= max_out:
+                break
+            if all(not (iou(cands[i][2], cands[j][2]) > f32(thr)) for j in keep):
+                keep.append(i)
+        return [cands[i] for i in keep]
+
+    B, A, C = cls_pred.shape
+    corner = np.empty_like(boxes)                            # NormalizeBoxes without shape (:488, :362-374)
+    corner[..., 0] = boxes[..., 1] - boxes[..., 3] / f32(2)
+    corner[..., 1] = boxes[..., 0] - boxes[..., 2] / f32(2)
+    corner[..., 2] = boxes[..., 1] + boxes[..., 3] / f32(2)
+    corner[..., 3] = boxes[..., 0] + boxes[..., 2] / f32(2)
+    per_id, seen = {}, []                                    # :491-520: tf.where row-major, tf.unique first occurrence
+    for b in range(B):
+        for a in range(A):
+            for c in range(C):
+                if cls_pred[b, a, c] >= f32(min_conf):
+                    key = b * (C + 1) + c
+                    if key not in per_id:
+                        per_id[key] = []
+                        seen.append(key)
+                    per_id[key].append((cls_pred[b, a, c], a, corner[b, a], (b, a, c)))
+    stage1 = []
+    for key in seen:                                         # :522 map_fn, :507-514
+        stage1 += nms(per_id[key], nms_iou)
+    final = []
+    for b in range(B):                                       # :531-555
+        cand = [(s, pos, cb, pl) for pos, (s, _, cb, pl) in enumerate(stage1) if pl[0] == b]
+        final += [pl for (_, _, _, pl) in nms(cand, post_iou)]
+    return np.array(final, np.int64).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("seed,frac", [(0, 0.02), (1, 0.10), (2, 0.30)])
+def test_detection_proposal_vs_loop_form(seed, frac):
+    rng = np.random.default_rng(seed)
+    B, C = 2, 5
+    table = O.prior_table([8, 16, 32, 64, 128], [32, 64, 128, 256, 512], [2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)],
+                          [1 / 3, 1 / 2, 1, 2, 3])
+    pri = O.prior_boxes(table, 64, 64)
+    A = pri.shape[0]
+    cls = rng.uniform(0, 0.45, (B, A, C)).astype(np.float32)
+    hot = rng.random((B, A, C)) < frac
+    cls[hot] = (0.5 + 0.5 * (rng.permutation(int(hot.sum())) + 0.5) / max(int(hot.sum()), 1)).astype(np.float32)
+    cls[0, 5, 1] = cls[0, 300, 1] = cls[1, 7, 2] = np.float32(0.99)       # equal scores: lower index first on both sides
+    boxes = O.restore_boxes((rng.normal(size=(B, A, 4)) * 0.2).astype(np.float32), pri[None])
+    for max_out in (100, 7):
+        _, kept = O.detection_proposal(cls, boxes, 0.5, 0.4, 0.6, max_out)
+        np.testing.assert_array_equal(kept, _detection_proposal_loops(cls, boxes, 0.5, 0.4, 0.6, max_out))
+
+
+def test_order_stable_fixture_helpers():
+    """oracle/fixtures.py: threshold in the widest score gap, logit scaling of the class output kernels, and the
+    perturbation check that backs the full-size "indices bit-exact" tests."""
+    from oracle import fixtures as FX
+    c = np.array([[[0.40], [0.470], [0.471], [0.53], [0.54], [0.9]]], np.float32)
+    thr, gap = FX.gap_threshold(c)
+    assert 0.471 < thr < 0.53 and abs(gap - (0.53 - 0.471)) < 1e-6
+    w = {"classification_sub_net/block0/output/kernel": np.ones((3, 3, 4, 5), np.float32),
+         "classification_sub_net/block0/output/bias": np.ones(5, np.float32), "other/kernel": np.ones(3, np.float32)}
+    w2 = FX.scale_cls_logits(w, 3.5)
+    assert float(w2["classification_sub_net/block0/output/kernel"][0, 0, 0, 0]) == 3.5
+    assert w2["classification_sub_net/block0/output/bias"] is w["classification_sub_net/block0/output/bias"]
+    assert w2["other/kernel"] is w["other/kernel"]
+    from masklab_hip import ModelConfiguration
+    cfg = ModelConfiguration()
+    pri = FX.boxes_from(cfg, np.zeros((1, 15 * (8 * 8 + 4 * 4 + 2 * 2 + 1 + 1), 4), np.float32), 64, 64)
+    cls = np.zeros((1, pri.shape[1], 5), np.float32)
+    cls[0, [3, 400, 900], 2] = [0.9, 0.8, 0.7]                  # far apart in score: stable
+    kept, same = FX.order_stability(cfg, cls, pri, 0.5, trials=4)
+    assert same == 4 and len(kept) >= 1
+    cls[0, 401, 2] = np.float32(0.8) + np.float32(1e-6)         # a near-tie between overlapping neighbours: unstable
+    _, same = FX.order_stability(cfg, cls, pri, 0.5, trials=16)
+    assert same < 16

@@ -34,6 +34,13 @@ def _worker(rank, world, port, q):
             for i in range(int(counts[b])):
                 prop[b, i] = torch.tensor([rank, b, i, 1.0, float(i % 5), 0.9 - 0.1 * i])
         allp, allc = parallel.all_gather_detections(prop, counts)
+        # the hot path hands over the record the detection kernel wrote (one [B, cap*6+1] tensor) and gets views back
+        payload = parallel.pack_payload(prop, counts)
+        g = parallel.AsyncDetectionGather("cpu")
+        vp, vc = g.wait(g.launch(payload, cap))
+        assert torch.equal(vp, allp) and torch.equal(vc, allc) and vc.dtype == torch.int32
+        p3, c3 = parallel.all_gather_detections(prop, counts, payload=payload)
+        assert torch.equal(p3, allp) and torch.equal(c3, allc)
         seg = torch.full((2, 3, 3, 3), float(rank))
         (allseg,) = parallel.all_gather_outputs([seg])
         q.put((rank, allp.numpy(), allc.numpy(), allseg.numpy()))
@@ -70,6 +77,10 @@ def test_single_process_passthrough_and_shard_errors():
     p, c = torch.zeros(2, 3, 6), torch.zeros(2, dtype=torch.int32)
     a, b = parallel.all_gather_detections(p, c)
     assert a is p and b is c
+    pay = parallel.pack_payload(torch.arange(36.0).reshape(2, 3, 6), torch.tensor([3, 1], dtype=torch.int32))
+    p2, c2 = parallel.unpack_payload(pay, 3)
+    assert pay.shape == (2, 19) and p2.data_ptr() == pay.data_ptr() and c2.tolist() == [3, 1]
+    assert torch.equal(p2, torch.arange(36.0).reshape(2, 3, 6))
     with pytest.raises(ValueError):
         parallel.shard_batch(torch.zeros(5, 2, 2, 3), 0, 2)
     with pytest.raises(ValueError):
