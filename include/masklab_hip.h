@@ -73,7 +73,7 @@ typedef struct ml_conv2d_desc {
     int32_t act;            /* ML_ACT_*                                                       */
     int32_t group_cin_step; /* grouped 3x3: input-channel offset per 32-wide N block; else 0  */
     int32_t shuffle2x2;     /* 1: Conv2DTranspose epilogue, column = (a*2+b)*cout_real + o    */
-    int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32                    */
+    int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32, 4 = pipelined 1x1 (128x128) */
     int32_t math;           /* ML_MATH_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products);
                                ML_MATH_F16: operands rounded to fp16 on their way into LDS,
                                v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5);
@@ -96,6 +96,9 @@ int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace,
                         void *stream);
 /* N-tile width the auto heuristic picks for `cout` (host packs n_pad from it). */
 int ml_conv2d_ntile(int32_t cout, int32_t tile);
+/* 1 when ml_conv2d_multi_f32 runs this single problem on the persistent, tile-pipelined 1x1 kernel
+ * (conv1x1_pipe.hip: the short-K bottleneck convs of engine/backbone/ResNext.py:199-231), else 0. */
+int ml_conv2d_uses_pipe(const ml_conv2d_desc *d);
 
 /* ResNeXt grouped 3x3 (reference engine/backbone/ResNext.py:212-219: DepthwiseConv2D(depth_multiplier=c)
  * + SplitGroups/ReduceGroups/MergeGroups), c = channels per group in {4,8,16}, C % 64 == 0, on

@@ -581,6 +581,7 @@ splitk_reduce_kernel(const ReduceArgs args) {
 }
 
 int pick_tile(int cout, int tile) {
+    if (tile == 4) return 1;          // the pipelined 1x1 kernel works on 128x128 tiles like tile 1
     if (tile >= 1 && tile <= 3) return tile;
     if (cout <= 32) return 3;
     if (cout <= 64) return 2;
@@ -626,6 +627,13 @@ int validate(const ml_conv2d_desc &d) {
                    "conv2d: grouped input slices exceed buffer channels");
     }
     return ML_OK;
+}
+
+// where the pipelined 1x1 kernel is used by default: every 1x1 conv it can run with enough rows to keep its
+// persistent blocks busy (A/B per shape, gpurun_out/r02b_ab.log: x1.26-1.38 at K = 64, x1.23 at K = 128 + residual,
+// x1.05-1.18 at K = 256-512, x1.01-1.02 at K = 1024-2048; never slower)
+bool pipe_preferred(const ml_conv2d_desc &d) {
+    return d.KH == 1 && d.KW == 1 && (long long)d.B * d.H * d.W >= 4096;
 }
 
 // split-K heuristic: few tiles and a long K => slice K so that ~2 blocks per CU are in flight
@@ -718,12 +726,21 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
 
 }  // namespace
 
+int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible);     // conv1x1_pipe.hip
+
 extern "C" int ml_conv2d_ntile(int32_t cout, int32_t tile) {
     const int t = pick_tile(cout, tile);
     return t == 1 ? 128 : (t == 2 ? 64 : 32);
 }
 
 extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 64ll << 20; }
+
+int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d);                               // conv1x1_pipe.hip
+extern "C" int ml_conv2d_uses_pipe(const ml_conv2d_desc *d) {
+    if (!d) return 0;
+    if (d->tile == 4) return ml_conv1x1_pipe_eligible(*d);
+    return d->tile == 0 && pipe_preferred(*d) && ml_conv1x1_pipe_eligible(*d);
+}
 
 extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
                                    void *stream) {
@@ -740,6 +757,17 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void 
     ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // short-K 1x1 convs of the bottleneck blocks: the persistent, tile-pipelined kernel (tile = 4 forces it,
+    // tile = 1 keeps the generic kernel: A/B measurements and the parity tests of both)
+    if (n == 1 && (descs[0].tile == 0 || descs[0].tile == 4)) {
+        int took = 0;
+        if (descs[0].tile == 4 || pipe_preferred(descs[0])) {
+            const int rc = ml_conv1x1_pipe_try(descs[0], s, &took);
+            if (rc != ML_OK) return rc;
+            if (took) return ML_OK;
+        }
+        ML_REQUIRE(descs[0].tile != 4, "conv2d: tile = 4 (pipelined 1x1 kernel) does not apply to this problem");
+    }
     if (descs[0].math == ML_MATH_F16) {
         switch (t0) {
             case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s);

@@ -169,7 +169,10 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
                                                 in_coff, out_view)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
-    with _Prof(_conv_kernel_name(dc.p), flops, nbytes, shape):
+    name = _conv_kernel_name(dc.p)
+    if PROFILE is not None and lib.ml_conv2d_uses_pipe(C.byref(d)):
+        name = "conv1x1_pipe"
+    with _Prof(name, flops, nbytes, shape):
         _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret
 

@@ -18,6 +18,7 @@ SHAPES = [
     ("c2 1x1 64->256 sc", 8, 256, 256, 64, 256, 1, 1, False),
     ("c2 1x1 128->256 +res", 8, 256, 256, 128, 256, 1, 1, True),
     ("c2 1x1 256->128", 8, 256, 256, 256, 128, 1, 1, False),
+    ("c2 1x1 256->256 (c3b1)", 8, 256, 256, 256, 256, 1, 1, False),
     ("c3 1x1 256->512 +res", 8, 128, 128, 256, 512, 1, 1, True),
     ("c3 1x1 512->256", 8, 128, 128, 512, 256, 1, 1, False),
     ("c4 1x1 512->1024 +res", 8, 64, 64, 512, 1024, 1, 1, True),
@@ -30,10 +31,43 @@ SHAPES = [
 ]
 
 
+def ab_pipe(reps):
+    """generic kernel (tile 1) vs the pipelined 1x1 kernel (tile 4), interleaved rounds in one process."""
+    rng = np.random.default_rng(0)
+    for label, B, H, W, cin, cout, k, stride, res in SHAPES:
+        if k != 1 or stride != 1:
+            continue
+        x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
+        w = rng.normal(size=(1, 1, cin, cout)).astype(np.float32) * 0.05
+        dcs = {t: ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32), tile=t), "cuda") for t in (1, 4)}
+        r = torch.from_numpy(rng.normal(size=(B, H, W, cout)).astype(np.float32)).cuda() if res else None
+        out = torch.empty((B, H, W, cout), device="cuda")
+        best = {1: [], 4: []}
+        for rnd_ in range(5):
+            for t in (1, 4):
+                for _ in range(2):
+                    ops.conv2d(x, dcs[t], padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(reps):
+                    ops.conv2d(x, dcs[t], padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+                e.record()
+                torch.cuda.synchronize()
+                best[t].append(s.elapsed_time(e) / reps)
+        gf = 2.0 * out.numel() * cin / 1e9
+        mb = 4 * (x.numel() + out.numel() * (2 if res else 1)) / 1e6
+        m1, m4 = np.median(best[1]), np.median(best[4])
+        print(f"{label:28s} generic {1e3 * m1:7.1f} us {gf / m1:6.1f} TF | pipe {1e3 * m4:7.1f} us {gf / m4:6.1f} TF "
+              f"{mb / m4:6.0f} GB/s | x{m1 / m4:.2f}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--ab-pipe", action="store_true")
     args = ap.parse_args()
+    if args.ab_pipe:
+        return ab_pipe(args.reps)
     rng = np.random.default_rng(0)
     tot_ms, tot_gf = 0.0, 0.0
     for label, B, H, W, cin, cout, k, stride, res in SHAPES:

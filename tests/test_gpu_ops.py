@@ -68,6 +68,58 @@ def test_conv2d_dense(k, cin, cout, stride, padding, dil, act, hw):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,hw,B,res,act,in_slice", [
+    (64, 128, (40, 24), 2, False, "relu", False),       # K = 64: two chunks, FIRST then LAST
+    (64, 256, (37, 29), 3, False, "relu", False),       # ragged M (3219 rows: partial last panel), two N tiles
+    (128, 256, (32, 32), 2, True, "relu", False),       # bottleneck exit: residual + ReLU
+    (256, 128, (33, 31), 2, False, None, True),         # reads a channel slice of a wider buffer, linear
+    (256, 512, (16, 16), 2, True, "relu6", False),      # few panels: N tiles split over work units
+    (512, 1024, (8, 8), 1, True, "relu", False),        # one panel, 8 N tiles in 8 units
+    (96, 128, (20, 20), 1, False, "relu", False),       # K = 96: three chunks
+])
+def test_conv1x1_pipelined_kernel(cin, cout, hw, B, res, act, in_slice):
+    """csrc/conv1x1_pipe.hip (tile = 4): the persistent, tile-pipelined 1x1 conv of the ResNeXt bottleneck blocks
+    (reference engine/backbone/ResNext.py:199-231) against the oracle, and against the generic kernel (tile = 1)."""
+    from masklab_hip import _lib, ops, packing
+    x = rnd(B, hw[0], hw[1], cin + (32 if in_slice else 0))
+    xin = x[..., 32:] if in_slice else x
+    w, b = rnd(1, 1, cin, cout, scale=1.0 / np.sqrt(cin)), rnd(cout)
+    r = rnd(B, hw[0], hw[1], cout) if res else None
+    ref = T.conv2d(xin.astype(np.float64), w, b, 1, "valid", 1)
+    if res:
+        ref = ref + r
+    ref = {"relu": T.relu, "relu6": T.relu6, None: lambda v: v}[act](ref)
+    outs = {}
+    for tile in (4, 1):
+        dc = ops.DeviceConv(packing.pack_dense(w, b, tile=tile), "cuda")
+        got = ops.conv2d(dev(x), dc, padding="valid", act=_lib.ACT_BY_NAME[act], residual=dev(r) if res else None,
+                         in_coff=32 if in_slice else 0)
+        outs[tile] = host(got)
+        np.testing.assert_allclose(outs[tile], ref, rtol=0, atol=3e-5, err_msg=f"tile={tile}")
+    np.testing.assert_allclose(outs[4], outs[1], rtol=0, atol=1e-5)          # same products; bias / residual enter the chain at a different place
+    # writing into a channel slice of a wider buffer leaves the other channels alone
+    buf = torch.full((B, hw[0], hw[1], cout + 128), 7.0, device="cuda")
+    dc = ops.DeviceConv(packing.pack_dense(w, b, tile=4), "cuda")
+    if not res:
+        ops.conv2d(dev(x), dc, padding="valid", act=_lib.ACT_BY_NAME[act], out=buf, out_coff=128,
+                   in_coff=32 if in_slice else 0)
+        hb = host(buf)
+        assert np.all(hb[..., :128] == 7.0)
+        np.testing.assert_array_equal(hb[..., 128:], outs[4])
+
+
+def test_conv1x1_pipelined_kernel_is_the_default_for_short_k():
+    from masklab_hip import _lib, ops, packing
+    lib = _lib.load()
+    x = dev(rnd(1, 16, 16, 128))
+    for cout, tile, want in ((256, 0, 1), (256, 1, 0), (75, 0, 0), (256, 4, 1)):
+        d, _, _ = ops._conv_desc(x, ops.DeviceConv(packing.pack_dense(rnd(1, 1, 128, cout), None, tile=tile), "cuda"),
+                                 padding="valid")
+        assert lib.ml_conv2d_uses_pipe(d) == want, (cout, tile)
+    with pytest.raises(RuntimeError, match="tile = 4"):       # forcing it onto a 3x3 conv is an error, not a fallback
+        ops.conv2d(dev(rnd(1, 8, 8, 64)), ops.DeviceConv(packing.pack_dense(rnd(3, 3, 64, 128), None, tile=4), "cuda"))
+
+
 def test_conv2d_residual_and_concat_slice():
     from masklab_hip import _lib, ops, packing
     x, res = rnd(2, 12, 12, 64), rnd(2, 12, 12, 96)
