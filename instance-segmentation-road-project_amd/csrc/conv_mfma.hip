@@ -629,11 +629,12 @@ int validate(const ml_conv2d_desc &d) {
     return ML_OK;
 }
 
-// where the pipelined 1x1 kernel is used by default: every 1x1 conv it can run with enough rows to keep its
-// persistent blocks busy (A/B per shape, gpurun_out/r02b_ab.log: x1.26-1.38 at K = 64, x1.23 at K = 128 + residual,
-// x1.05-1.18 at K = 256-512, x1.01-1.02 at K = 1024-2048; never slower)
+// where the pipelined 1x1 kernel is used by default (per-launch A/B inside the model, gpurun_out/launches_r02a vs r02d:
+// x1.2-1.3 at K = 64-128, x1.05-1.15 at K = 256-512, nothing at K >= 1024; it loses where there are few rows -- no
+// split-K: 64 panels of K = 2048 took 131 us against 50).  The rule looks at ONE image's pixel count, never at the
+// batch: an image's results must not depend on the shard it is computed in (tests/test_gpu_model.py).
 bool pipe_preferred(const ml_conv2d_desc &d) {
-    return d.KH == 1 && d.KW == 1 && (long long)d.B * d.H * d.W >= 4096;
+    return d.KH == 1 && d.KW == 1 && d.span <= 512 && (long long)d.H * d.W >= 4096;
 }
 
 // split-K heuristic: few tiles and a long K => slice K so that ~2 blocks per CU are in flight

@@ -111,11 +111,16 @@ def test_conv1x1_pipelined_kernel(cin, cout, hw, B, res, act, in_slice):
 def test_conv1x1_pipelined_kernel_is_the_default_for_short_k():
     from masklab_hip import _lib, ops, packing
     lib = _lib.load()
-    x = dev(rnd(1, 16, 16, 128))
+    x = dev(rnd(1, 64, 64, 128))
     for cout, tile, want in ((256, 0, 1), (256, 1, 0), (75, 0, 0), (256, 4, 1)):
         d, _, _ = ops._conv_desc(x, ops.DeviceConv(packing.pack_dense(rnd(1, 1, 128, cout), None, tile=tile), "cuda"),
                                  padding="valid")
         assert lib.ml_conv2d_uses_pipe(d) == want, (cout, tile)
+    # the choice looks at one image's pixel count, never at the batch (an image's result must not depend on its shard)
+    for B, hw, want in ((1, 32, 0), (64, 32, 0), (1, 64, 1)):
+        d, _, _ = ops._conv_desc(dev(rnd(B, hw, hw, 128)), ops.DeviceConv(packing.pack_dense(rnd(1, 1, 128, 256), None), "cuda"),
+                                 padding="valid")
+        assert lib.ml_conv2d_uses_pipe(d) == want, (B, hw)
     with pytest.raises(RuntimeError, match="tile = 4"):       # forcing it onto a 3x3 conv is an error, not a fallback
         ops.conv2d(dev(rnd(1, 8, 8, 64)), ops.DeviceConv(packing.pack_dense(rnd(3, 3, 64, 128), None, tile=4), "cuda"))
 
