@@ -245,3 +245,119 @@ def test_keras_h5_converter_walks_and_matches_names():
     bad[second] = np.zeros((1,), np.float32)
     _, rep = conv.match_to_model(bad, specs)
     assert rep["missing"] == [first] and rep["shape_mismatch"][0][0] == second
+
+
+def _reference_named(weights, cfg, uid_start):
+    """Re-key a weight dict of THIS package the way the reference's Keras model names the same tensors: sub-layers the
+    reference leaves unnamed get Keras' automatic `<class>_N` names, N from one session-wide counter per class in
+    CONSTRUCTION order (engine/retinamasklab.py:40-198 build order; constructors detection.py:39-48,109-130,
+    instance.py:177-201, semantic.py:199-219), Dense layers of SqueezeExcite at first CALL (misc.py:34-40, call order
+    of construct_inference_network :443-486).  Written from the reference constructors, not from the converter."""
+    import collections
+    uid = collections.defaultdict(int, uid_start)
+
+    def auto(cls):
+        n = uid[cls]
+        uid[cls] += 1
+        return cls if n == 0 else f"{cls}_{n}"
+
+    det, ins, sem = cfg.detection, cfg.instance, cfg.semantic
+    pre = {}                                            # our sub-layer prefix -> reference prefix
+    se_calls = []                                       # SqueezeExcite instances in call order
+    for p in (5, 4, 3):
+        pre[f"feature_pyramid/C{p}_lateral"] = "feature_pyramid/" + auto("conv2d")
+
+    def tower(scope, base, depth, se, sep):
+        for i in range(depth):
+            if se:
+                pre[f"{base}/se{i}"] = f"{scope}/" + auto("squeeze_excite")
+                se_calls.append(f"{base}/se{i}")
+            if sep:
+                pre[f"{base}/sep{i}"] = f"{scope}/" + auto("mobile_separable_conv2d")
+            else:
+                pre[f"{base}/conv{i}"] = f"{scope}/" + auto("conv2d")
+            pre[f"{base}/gn{i}"] = f"{scope}/" + auto("group_normalization")
+
+    for scope, se in (("classification_sub_net", det.use_squeeze_excite),
+                      ("box_regression_sub_net", det.use_separable_conv)):          # builder quirk :95
+        for b in range(5):
+            tower(scope, f"{scope}/block{b}", det.num_depth, se, det.use_separable_conv)
+            pre[f"{scope}/block{b}/output"] = f"{scope}/" + auto("conv2d")
+    for b in range(ins.max_k + 1):
+        tower("mask_sub_net", f"mask_sub_net/block{b}", ins.num_depth, ins.use_squeeze_excite, ins.use_separable_conv)
+        pre[f"mask_sub_net/block{b}/deconv"] = "mask_sub_net/" + auto("conv2d_transpose")
+        pre[f"mask_sub_net/block{b}/output"] = "mask_sub_net/" + auto("conv2d")
+    tower("segmentation_sub_net", "segmentation_sub_net", sem.num_depth, sem.use_squeeze_excite, sem.use_separable_conv)
+    pre["segmentation_sub_net/output"] = "segmentation_sub_net/" + auto("conv2d")
+    dense = {}
+    for se in se_calls:                                 # (mask head before the decoder: retinamasklab.py:470 then :486)
+        dense[se] = (auto("dense"), auto("dense"))
+    out = {}
+    for k, v in weights.items():
+        parts = k.split("/")
+        new = None
+        for cut in range(len(parts) - 1, 0, -1):
+            head = "/".join(parts[:cut])
+            if head in pre:
+                new = pre[head] + "/" + "/".join(parts[cut:])
+                if head in dense:                       # .../se{i}/dense{1,2}/kernel
+                    new = pre[head] + "/" + dense[head][int(parts[cut][5:]) - 1] + "/" + "/".join(parts[cut + 1:])
+                break
+            m = re.match(r"^(.*/sep\d+)_(.+)$", head)
+            if m and m.group(1) in pre and cut == len(parts) - 1:
+                new = f"{pre[m.group(1)]}/SeparableConv2d_{m.group(2)}/" + parts[-1]
+                break
+        if new is None:
+            if parts[0].startswith(("aspp_", "concat_projection")):
+                new = "aspp_network/" + k               # explicit names inside ASPPNetwork (semantic.py:112-136)
+            elif parts[0].startswith("skip_projection"):
+                new = "segmentation_sub_net/" + k       # semantic.py:199-201
+            else:
+                new = k
+        assert new not in out, new
+        out[new] = v
+    return out
+
+
+@pytest.mark.parametrize("flags,uid_start", [
+    ({}, {}),                                                                   # default heads, fresh session
+    ({}, {"conv2d": 7, "group_normalization": 3, "conv2d_transpose": 2}),       # session not cleared before the build
+    ({"se": True, "sep": True}, {"dense": 5, "squeeze_excite": 1}),             # the optional tower variants
+])
+def test_keras_h5_converter_maps_reference_auto_names_by_creation_order(flags, uid_start):
+    """a REAL checkpoint names tower / lateral / mask-head sub-layers `conv2d_N`,
+    `group_normalization_N`, ... (the reference never names them); the converter must map them onto this package's
+    hierarchical names by creation order, whatever N the session counters started from."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "convert_keras_h5", os.path.join(os.path.dirname(__file__), "..", "tools", "convert_keras_h5.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    from masklab_hip import ModelConfiguration, retinamasklab as R
+    cfg = ModelConfiguration()
+    cfg.backbone.backbone_type = "mobilenet"
+    if flags.get("se"):
+        cfg.detection.use_squeeze_excite = cfg.instance.use_squeeze_excite = cfg.semantic.use_squeeze_excite = True
+    if flags.get("sep"):
+        cfg.detection.use_separable_conv = cfg.instance.use_separable_conv = True
+    _, model = R.construct_masklab_networks(cfg)
+    w = model.init_weights(2)
+    specs = {k: tuple(v.shape) for k, v in model.weight_specs().items()}
+    ref_named = _reference_named(w, cfg, uid_start)
+    assert any(re.search(r"/conv2d_\d+/kernel$", k) for k in ref_named)          # the stand-in really is auto-named
+    assert not any("/block" in k for k in ref_named)
+    got = conv.collect_h5_weights(_fake_keras_file(ref_named))
+    assert set(got) == set(ref_named)
+    # without the creation-order mapping nothing under the towers is found (what round 1's converter did)
+    _, rep0 = conv.match_to_model(got, specs)
+    assert len(rep0["missing"]) > 100
+    matched, rep = conv.match_to_model(conv.rename_keras_auto_names(got, specs), specs)
+    assert rep["missing"] == [] and rep["shape_mismatch"] == [] and rep["unexpected"] == []
+    for k in w:
+        np.testing.assert_array_equal(matched[k], w[k], err_msg=k)
+    # a checkpoint of a different head configuration is refused, not mis-assigned
+    fewer = {k: v for k, v in got.items() if "/group_normalization" not in k or not k.startswith("mask_sub_net")}
+    dropped = sorted(k for k in got if k.startswith("mask_sub_net/group_normalization"))[:2]
+    fewer = {k: v for k, v in got.items() if k not in dropped}
+    with pytest.raises(ValueError, match="different head configuration"):
+        conv.rename_keras_auto_names(fewer, specs)

@@ -4,7 +4,9 @@
 `masklab_hip.retinamasklab.load_masklab_inference_model_from_weights` reads.
 
 The reference re-wires a loaded Keras model by layer-name regexes (:515-586); here the same names key
-the tensors directly: `<layer>/<sub-layer>/.../<weight>` with the TF suffix `:0` dropped.  Keras stores
+the tensors directly: `<layer>/<sub-layer>/.../<weight>` with the TF suffix `:0` dropped; the sub-layers the
+reference leaves to Keras' automatic numbering (`conv2d_7`, `group_normalization_3`, ...) are mapped onto this
+package's hierarchical names by creation order (rename_keras_auto_names).  Keras stores
   /[model_weights/]<top layer>  attrs['weight_names'] = [b'<scope>/<weight>:0', ...]  + one dataset each
 so no graph has to be rebuilt: walk the groups, strip the suffix, and check every tensor the target model
 declares (name, shape) is present.
@@ -44,6 +46,128 @@ def collect_h5_weights(root):
             if key in out:
                 raise ValueError(f"duplicate weight name in the h5 file: {key}")
             out[key] = np.asarray(node)
+    return out
+
+
+# ------------------------------------------------------------------ Keras auto-numbered sub-layer names
+# The reference does not name the sub-layers of its custom layers: FeaturePyramid's laterals (detection.py:42), the
+# tower / mask-head / decoder convs and GroupNormalizations (detection.py:109-130,179-202, instance.py:177-201,
+# semantic.py:205-219) and SqueezeExcite's Dense pair (misc.py:34-40) get Keras' automatic names
+# `conv2d_N`, `group_normalization_N`, `conv2d_transpose_N`, `squeeze_excite_N`, `mobile_separable_conv2d_N`,
+# `dense_N`, with N from ONE counter per class for the whole session -- so N itself depends on what was built before,
+# but inside one custom layer the ORDER of the N's is the constructor's creation order.  This package gives the same
+# sub-layers hierarchical names (block{b}/conv{i} ...); the two are matched by that order, per scope and per class.
+import re
+
+_SCOPES = ("feature_pyramid", "classification_sub_net", "box_regression_sub_net", "mask_sub_net",
+           "segmentation_sub_net")
+_AUTO = ("conv2d_transpose", "conv2d", "group_normalization", "squeeze_excite", "mobile_separable_conv2d",
+         "depthwise_conv2d", "dense")
+_AUTO_RE = re.compile(r"^(%s)(?:_(\d+))?$" % "|".join(_AUTO))
+_SEP_PARTS = ("expand_conv", "expand_GN", "depthwise_GN", "depthwise", "squeeze_conv", "squeeze_GN")
+
+
+def _our_sublayers(specs):
+    """{scope: {keras class: [our sub-layer prefix, ...] in the reference's creation order}} from this package's
+    weight names (the naming convention of masklab_hip/layers/*.py)."""
+    out = {}
+
+    def add(scope, cls, order, prefix):
+        lst = out.setdefault(scope, {}).setdefault(cls, [])
+        if (order, prefix) not in lst:
+            lst.append((order, prefix))
+
+    for name in specs:
+        parts = name.split("/")
+        scope = parts[0]
+        if scope not in _SCOPES or len(parts) < 3:
+            continue
+        if scope == "feature_pyramid":
+            m = re.match(r"^C(\d+)_lateral$", parts[1])
+            if m:                                   # created for strides in DESCENDING order (detection.py:39-43)
+                add(scope, "conv2d", (-int(m.group(1)),), f"{scope}/{parts[1]}")
+            continue
+        b = 0
+        rest = parts[1:-1]
+        if re.match(r"^block\d+$", rest[0]):
+            b = int(rest[0][5:])
+            base = f"{scope}/{rest[0]}"
+            rest = rest[1:]
+        else:
+            base = scope
+        if not rest:
+            continue
+        sub = rest[0]
+        m = re.match(r"^(conv|gn|se)(\d+)$", sub)
+        ms = re.match(r"^sep(\d+)_(%s)$" % "|".join(_SEP_PARTS), sub)
+        if m:
+            kind, i = m.group(1), int(m.group(2))
+            cls = {"conv": "conv2d", "gn": "group_normalization", "se": "squeeze_excite"}[kind]
+            add(scope, cls, (b, i, 0), f"{base}/{sub}")
+        elif ms:
+            add(scope, "mobile_separable_conv2d", (b, int(ms.group(1)), 0), f"{base}/sep{ms.group(1)}")
+        elif sub == "deconv":
+            add(scope, "conv2d_transpose", (b, 0, 0), f"{base}/deconv")
+        elif sub == "output":                      # created after the block's tower (and after the deconv)
+            add(scope, "conv2d", (b, 1 << 20, 0), f"{base}/output")
+    return {sc: {cls: [p for _, p in sorted(lst)] for cls, lst in d.items()} for sc, d in out.items()}
+
+
+def rename_keras_auto_names(weights, specs):
+    """Rewrite the keys of a reference-named weight dict (`<...>/<scope>[_k]/<auto name>/.../<weight>`) to this
+    package's names.  Keys that are not under an auto-named sub-layer are returned unchanged.  Raises ValueError
+    when a scope holds a different number of auto-named sub-layers of some class than the model declares."""
+    ours = _our_sublayers(specs)
+    found = {}                                      # (scope, class) -> {N: file prefix up to the sub-layer}
+    located = []                                    # (key, scope, class, N, remainder parts)
+    for key in weights:
+        parts = key.split("/")
+        for pos, comp in enumerate(parts[:-2]):
+            sc = re.sub(r"_\d+$", "", comp)
+            if sc in _SCOPES and comp in (sc,) + tuple(f"{sc}_{k}" for k in range(1, 1000)):
+                m = _AUTO_RE.match(parts[pos + 1])
+                if m:
+                    n = int(m.group(2) or 0)
+                    found.setdefault((sc, m.group(1)), {})[n] = "/".join(parts[:pos + 2])
+                    located.append((key, sc, m.group(1), n, parts[pos + 2:]))
+                break
+    rank = {}
+    for (sc, cls), by_n in found.items():
+        want = ours.get(sc, {}).get(cls, [])
+        if len(by_n) != len(want):
+            raise ValueError(f"checkpoint has {len(by_n)} auto-named '{cls}' sub-layers under '{sc}', the model "
+                             f"declares {len(want)}: different head configuration (num_depth / num_blocks / "
+                             f"use_squeeze_excite / use_separable_conv)?")
+        for r, n in enumerate(sorted(by_n)):
+            rank[(sc, cls, n)] = want[r]
+    out = dict(weights)
+    dense_seen = {}
+    for key, sc, cls, n, rest in located:
+        target = rank[(sc, cls, n)]
+        if cls == "squeeze_excite":
+            # .../squeeze_excite_k/dense_m/kernel: the two Dense layers are created in build() in order (misc.py:34-40)
+            md = _AUTO_RE.match(rest[0])
+            if not md or md.group(1) != "dense":
+                raise ValueError(f"unexpected tensor inside a SqueezeExcite scope: {key}")
+            dense_seen.setdefault(target, set()).add(int(md.group(2) or 0))
+            continue
+        if cls == "mobile_separable_conv2d":
+            # explicit inner names 'SeparableConv2d_<part>' (misc.py:73-93) -> '<block>/sep{i}_<part>'
+            inner = re.sub(r"^SeparableConv2d_", "", rest[0])
+            new = f"{target}_{inner}/" + "/".join(rest[1:])
+        else:
+            new = target + "/" + "/".join(rest)
+        del out[key]
+        out[new] = weights[key]
+    for key, sc, cls, n, rest in located:
+        if cls != "squeeze_excite":
+            continue
+        target = rank[(sc, cls, n)]
+        order = sorted(dense_seen[target])
+        md = _AUTO_RE.match(rest[0])
+        which = order.index(int(md.group(2) or 0)) + 1
+        del out[key]
+        out[f"{target}/dense{which}/" + "/".join(rest[1:])] = weights[key]
     return out
 
 
@@ -106,7 +230,8 @@ def main(argv=None):
                          "holds the checkpoint); the .npz it writes has no such dependency")
     with h5py.File(args.h5_path, "r") as f:
         weights = collect_h5_weights(f)
-    matched, report = match_to_model(weights, model_specs(args.backbone))
+    specs = model_specs(args.backbone)
+    matched, report = match_to_model(rename_keras_auto_names(weights, specs), specs)
     for k in ("missing", "shape_mismatch"):
         for item in report[k]:
             print(f"{k}: {item}", file=sys.stderr)
