@@ -602,8 +602,8 @@ int validate(const ml_conv2d_desc &d) {
     ML_REQUIRE(d.cout > 0 && d.out_cstride > 0 && d.out_coff >= 0 && d.out_bstride >= 0, "conv2d: bad output channels");
     ML_REQUIRE((long long)d.B * d.H * d.W < (1ll << 31) / 2, "conv2d: too many input pixels for int32 indexing");
     ML_REQUIRE((long long)d.B * d.Ho * d.Wo < (1ll << 31) - 256, "conv2d: too many output pixels");
-    ML_REQUIRE((long long)d.B * d.H * d.W * d.in_cstride * 4 < (1ll << 31),
-               "conv2d: input tensor must be < 2 GiB (32-bit buffer offsets): shard the batch");
+    ML_REQUIRE((long long)d.H * d.W * d.in_cstride * 4 < (1ll << 31),
+               "conv2d: ONE image of the input must be < 2 GiB (32-bit buffer offsets inside an image group)");
     ML_REQUIRE((long long)d.n_pad * d.KH * d.KW * d.span_pad * 4 < (1ll << 31), "conv2d: weight tensor must be < 2 GiB");
     if (d.shuffle2x2) {
         ML_REQUIRE(d.cout % 4 == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Ho == d.H && d.Wo == d.W,
@@ -743,9 +743,60 @@ extern "C" int ml_conv2d_uses_pipe(const ml_conv2d_desc *d) {
     return d->tile == 0 && pipe_preferred(*d) && ml_conv1x1_pipe_eligible(*d);
 }
 
-extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
+// The generic kernel addresses its input through 32-bit buffer offsets: a problem whose activation is >= 2 GiB (e.g. 32
+// images of 256x256x256 fp32, the largest batch the reference's MoldBatch takes, engine/layers/misc.py:273-284) is
+// cut into groups of whole images, each its own problem of the same launch.  -> number of problems written, or < 0.
+static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_desc *out, int cap) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const ml_conv2d_desc &d = descs[i];
+        const long long img_bytes = (long long)d.H * d.W * d.in_cstride * 4;
+        const long long limit = (1ll << 31) - 16;
+        long long per = img_bytes > 0 ? limit / img_bytes : d.B;
+        if (per < 1) per = 1;
+        if (per >= d.B) {
+            if (m >= cap) return -1;
+            out[m++] = d;
+            continue;
+        }
+        const long long in_img = (long long)d.H * d.W * d.in_cstride;
+        const long long out_pix = d.shuffle2x2 ? 4ll * d.Ho * d.Wo : (long long)d.Ho * d.Wo;
+        const long long out_img = d.out_bstride ? d.out_bstride : out_pix * d.out_cstride;
+        const long long res_img = (long long)d.Ho * d.Wo * d.res_cstride;
+        for (long long b0 = 0; b0 < d.B; b0 += per) {
+            if (m >= cap) return -1;
+            ml_conv2d_desc g = d;
+            g.B = (int)(d.B - b0 < per ? d.B - b0 : per);
+            g.in = d.in + b0 * in_img;
+            g.out = d.out + b0 * out_img;
+            if (d.residual) g.residual = d.residual + b0 * res_img;
+            out[m++] = g;
+        }
+    }
+    return m;
+}
+
+extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in, void *workspace, int64_t workspace_bytes,
                                    void *stream) {
-    ML_REQUIRE(descs != nullptr && n >= 1 && n <= MAXP, "conv2d: need 1..%d problems", MAXP);
+    ML_REQUIRE(descs_in != nullptr && n_in >= 1 && n_in <= MAXP, "conv2d: need 1..%d problems", MAXP);
+    // the persistent 1x1 kernel has no tensor-size limit: try it before any splitting
+    if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4)) {
+        const int rc0 = validate(descs_in[0]);
+        if (rc0 != ML_OK) return rc0;
+        ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16, "conv2d: unknown math mode %d",
+                   descs_in[0].math);
+        int took = 0;
+        if (descs_in[0].tile == 4 || pipe_preferred(descs_in[0])) {
+            const int rc = ml_conv1x1_pipe_try(descs_in[0], reinterpret_cast<hipStream_t>(stream), &took);
+            if (rc != ML_OK) return rc;
+            if (took) return ML_OK;
+        }
+        ML_REQUIRE(descs_in[0].tile != 4, "conv2d: tile = 4 (pipelined 1x1 kernel) does not apply to this problem");
+    }
+    ml_conv2d_desc split[MAXP];
+    const int n = split_by_image_groups(descs_in, n_in, split, MAXP);
+    ML_REQUIRE(n >= 1, "conv2d: too many >= 2 GiB activations in one launch (more than %d image groups)", MAXP);
+    const ml_conv2d_desc *descs = split;
     int t0 = 0;
     for (int i = 0; i < n; ++i) {
         const int rc = validate(descs[i]);
@@ -758,17 +809,6 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void 
     ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // short-K 1x1 convs of the bottleneck blocks: the persistent, tile-pipelined kernel (tile = 4 forces it,
-    // tile = 1 keeps the generic kernel: A/B measurements and the parity tests of both)
-    if (n == 1 && (descs[0].tile == 0 || descs[0].tile == 4)) {
-        int took = 0;
-        if (descs[0].tile == 4 || pipe_preferred(descs[0])) {
-            const int rc = ml_conv1x1_pipe_try(descs[0], s, &took);
-            if (rc != ML_OK) return rc;
-            if (took) return ML_OK;
-        }
-        ML_REQUIRE(descs[0].tile != 4, "conv2d: tile = 4 (pipelined 1x1 kernel) does not apply to this problem");
-    }
     if (descs[0].math == ML_MATH_F16) {
         switch (t0) {
             case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s);

@@ -287,3 +287,34 @@ def test_headline_size_indices_bit_exact(bt, size):
     n = int(det["counts"].cpu()[0])
     np.testing.assert_array_equal(det["kept"].cpu().numpy()[0, :n], kept_ref[:, 1:])      # same rows, same ORDER
     _check(model, got, want)
+
+
+def test_batch_32_at_1024_crosses_2gib_activations():
+    """The reference's MoldBatch takes up to 32 images per forward (engine/layers/misc.py:273-284).  At 1024x1024 the
+    ResNeXt-50 stem output and every 256-channel stage-2 tensor is 2.1 GB: past the 32-bit buffer offsets of the
+    generic conv kernel, which cuts such a problem into image groups (csrc/conv_mfma.hip split_by_image_groups); the
+    persistent 1x1 kernel advances 64-bit bases per tile.  Stem -> max-pool -> stage 2 (-> P6 on the 2.1 GB C2 ->
+    P7) for 32 images must equal the same images run one at a time bit for bit, and the oracle for the LAST image
+    (the one that sits behind the 2 GiB mark)."""
+    from masklab_hip import backbone as BB
+    from masklab_hip import keras_like as K
+    K.clear_session()
+    bb = BB.load_backbone("resnext50", backbone_outputs=("C2", "P6", "P7"), num_features=128)
+    w = K.init_weights(bb.weight_specs(), 0)
+    bb.load_weights(w, torch.device("cuda:0"))
+    B, S = 32, 1024
+    images = np.random.default_rng(4).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    dev_images = torch.from_numpy(images).cuda()
+    full = [t for t in bb(dev_images)]
+    torch.cuda.synchronize()
+    assert full[0].shape == (B, 256, 256, 256) and full[0].numel() * 4 > 2 ** 31
+    for b in (0, 17, 31):
+        one = bb(dev_images[b:b + 1].contiguous())
+        torch.cuda.synchronize()
+        for name, f, o in zip(bb.output_names, full, one):
+            assert torch.equal(f[b:b + 1], o), f"{name}: image {b} differs between the 32-image and the 1-image run"
+    names, ref = O.backbone_forward(images[31:32], w, "resnext50", ("C2", "P6", "P7"), literal_groups=False)
+    assert names == bb.output_names
+    for name, f, r in zip(names, full, ref):
+        err = float(np.max(np.abs(f[31:32].cpu().numpy().astype(np.float64) - r)))
+        assert err <= TOL, (name, err)
