@@ -51,7 +51,7 @@ WORKLOADS = {
     "mobilenet_full_b1_512": ("mobilenet", 1, 512, 512),         # BASELINE configs[0] shape
     "resnext50_full_b2_256": ("resnext50", 2, 256, 256),         # quick functional check
     "resnext101_full_b16_1280_f32": ("resnext101", 16, 1280, 1280),  # BASELINE configs[4] shape, fp32 path
-    "resnext101_full_b16_1280_f16": ("resnext101", 16, 1280, 1280),  # BASELINE configs[4]: fp16 path
+    "resnext101_full_b16_1280_f16": ("resnext101", 16, 1280, 1280),  # BASELINE configs[4]: fp16 MFMA path, fp16 storage
     "resnext50_full_b8_1024_f16": ("resnext50", 8, 1024, 1024),      # configs[2] shape on the fp16 path
 }
 # which roofline binds each kernel class
@@ -318,7 +318,7 @@ def main():
     backbone, B, H, W = WORKLOADS[args.workload]
     f16 = args.workload.endswith("_f16")
     if f16:
-        ops.set_conv_math("f16")
+        ops.set_conv_math("f16s")      # BASELINE config 5: fp16 MFMA, fp16 tensors in the backbone body, fp32 heads
     cfg, model, weights, hot_weights = build_model(backbone, device)
     images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
     if args.graph:

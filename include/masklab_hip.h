@@ -34,7 +34,7 @@ extern "C" {
 #define ML_E_NOGPU  (-3)   /* no gfx950 device visible                        */
 
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
-enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1 };
+enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2 };
 
 #define ML_ABI_VERSION 3              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
@@ -77,8 +77,14 @@ typedef struct ml_conv2d_desc {
     int32_t math;           /* ML_MATH_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products);
                                ML_MATH_F16: operands rounded to fp16 on their way into LDS,
                                v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5);
-                               tensors in HBM stay fp32 either way                              */
-    int32_t reserved0;      /* must be 0                                                      */
+                               tensors in HBM stay fp32 either way;
+                               ML_MATH_F16S: fp16 STORAGE -- in / wgt / residual / out point to IEEE half
+                               data (element counts and strides unchanged), fp16 MFMA, fp32 accumulation,
+                               bias (fp32) + residual + activation in fp32, one rounding at the store.
+                               1x1 stride-1 problems with cout % 128 == 0 and span % 64 == 0 only
+                               (the ResNeXt bottleneck convs: conv1x1_pipe.hip)                 */
+    int32_t out_f16;        /* ML_MATH_F16 only: 1 = `out` is IEEE half (the stem feeding an fp16-storage
+                               body); else 0                                                   */
     int64_t out_bstride;    /* floats between images in `out`; 0 = Ho*Wo*out_cstride (dense).
                                Lets a level's head write straight into the concatenated
                                [B, A, classes] prediction (detection.py:210-212 Reshape+Concatenate) */
@@ -107,6 +113,22 @@ int ml_conv2d_uses_pipe(const ml_conv2d_desc *d);
 int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo,
                     int32_t stride, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
+
+/* The same on fp16 tensors (in / out IEEE half, weights / bias / arithmetic fp32): the grouped conv of an
+ * fp16-STORAGE ResNeXt body (BASELINE config 5).                                                    */
+int ml_gconv3x3_f16(const void *in, const float *wgt, const float *bias, void *out,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo,
+                    int32_t stride, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
+
+/* ---------------------------------------------------------------- fp16-storage helpers (BASELINE config 5)
+ * ZeroPadding2D(1)+MaxPooling2D(3,2) on an fp16 map (ResNext.py:351-352; resnext.py:196-197), C % 8 == 0. */
+int ml_maxpool3x3s2_f16(const void *in, void *out, int32_t B, int32_t H, int32_t W, int32_t C,
+                        int32_t Ho, int32_t Wo, int32_t pad_t, int32_t pad_l, void *stream);
+/* out[b,oy,ox,:] = in[b,2oy,2ox,:] on fp16 [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C]: the sampling of a 1x1
+ * stride-2 conv (the strided shortcuts, ResNext.py:199-203), which then runs as a stride-1 ML_MATH_F16S conv. */
+int ml_subsample2_f16(const void *in, void *out, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+/* n halves -> n floats (the backbone taps handed to the fp32 heads), n % 8 == 0 */
+int ml_cast_f16_to_f32(const void *in, float *out, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------- depthwise / pooling
  * 3x3 DepthwiseConv2D (depth_multiplier 1), stride 1/2, dilation, explicit pads, +bias

@@ -351,7 +351,7 @@ conv_mfma_kernel(const MultiArgs args) {
     // Block-uniform: this tile takes the fast epilogue.  Then the bias is not added there (64 VALU adds per
     // thread) but is what the accumulators start from -- a lane's 16 registers of one 32x32 tile all belong
     // to ONE output column, so it costs one scalar load per tile column block.
-    const bool fast_blk = direct && out_vec_ok(p) && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID && (p.cout % 4 == 0);
+    const bool fast_blk = direct && (out_vec_ok(p) || p.out_f16) && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID && (p.cout % 4 == 0);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
@@ -506,7 +506,21 @@ conv_mfma_kernel(const MultiArgs args) {
             tile_v[i] = *reinterpret_cast<const f32x4 *>(lds + (r0 + i * ROWS_PER_PASS) * C_LD + c4);
         // (the bias is already in the accumulators; the clamp is one v_med3_f32 per element)
         const bool full = (m0 + BM <= M);            // block-uniform: no per-row range checks
-        if (full && !late_res && !p.out_bstride) {
+        if (p.out_f16) {
+            // fp16-storage body behind this conv (the stem): same tile ownership, 4 halves (8 bytes) per lane and row
+            _Float16 *oh = reinterpret_cast<_Float16 *>(p.out);
+#pragma unroll
+            for (int i = 0; i < E_ROWS; ++i) {
+                const int m = m0 + r0 + i * ROWS_PER_PASS;
+                if (m < M) {
+                    f32x4 v = tile_v[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                    const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<f16x4 *>(oh + off + (size_t)i * ROWS_PER_PASS * cs) = hv;
+                }
+            }
+        } else if (full && !late_res && !p.out_bstride) {
             float *op = p.out + off;
             const size_t step = (size_t)ROWS_PER_PASS * cs;
 #pragma unroll
@@ -614,6 +628,12 @@ int validate(const ml_conv2d_desc &d) {
         ML_REQUIRE(d.out_coff + d.cout <= d.out_cstride, "conv2d: output slice exceeds buffer channels");
     }
     if (d.residual) ML_REQUIRE(d.res_coff + d.cout <= d.res_cstride, "conv2d: residual slice exceeds buffer");
+    ML_REQUIRE(d.out_f16 == 0 || d.out_f16 == 1, "conv2d: out_f16 must be 0 or 1");
+    if (d.out_f16)
+        ML_REQUIRE(d.math == ML_MATH_F16 && !d.residual && !d.shuffle2x2 && d.out_bstride == 0 && d.act != ML_ACT_SIGMOID &&
+                       d.cout % 4 == 0 && d.out_cstride % 4 == 0 && d.out_coff % 4 == 0 && (((uintptr_t)d.out) & 7) == 0,
+                   "conv2d: out_f16 needs the fp16 MFMA mode, the dense fast epilogue (no residual / shuffle / batch "
+                   "stride / sigmoid) and 4-channel alignment");
     if (d.cpp_shift == 30) {
         ML_REQUIRE(d.in_coff + d.span <= d.in_cstride || d.group_cin_step > 0,
                    "conv2d: input slice exceeds buffer channels");
@@ -684,7 +704,7 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * 4);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
-        int splits = workspace ? choose_splits(launch_tiles, chunks) : 1;
+        int splits = (workspace && !d.out_f16) ? choose_splits(launch_tiles, chunks) : 1;
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
         if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
         P.cps = (chunks + splits - 1) / splits;
@@ -739,7 +759,7 @@ extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 64ll << 20; }
 int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d);                               // conv1x1_pipe.hip
 extern "C" int ml_conv2d_uses_pipe(const ml_conv2d_desc *d) {
     if (!d) return 0;
-    if (d->tile == 4) return ml_conv1x1_pipe_eligible(*d);
+    if (d->tile == 4 || d->math == ML_MATH_F16S) return ml_conv1x1_pipe_eligible(*d);
     return d->tile == 0 && pipe_preferred(*d) && ml_conv1x1_pipe_eligible(*d);
 }
 
@@ -783,10 +803,10 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4)) {
         const int rc0 = validate(descs_in[0]);
         if (rc0 != ML_OK) return rc0;
-        ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16, "conv2d: unknown math mode %d",
-                   descs_in[0].math);
+        ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16 || descs_in[0].math == ML_MATH_F16S,
+                   "conv2d: unknown math mode %d", descs_in[0].math);
         int took = 0;
-        if (descs_in[0].tile == 4 || pipe_preferred(descs_in[0])) {
+        if (descs_in[0].tile == 4 || descs_in[0].math == ML_MATH_F16S || pipe_preferred(descs_in[0])) {
             const int rc = ml_conv1x1_pipe_try(descs_in[0], reinterpret_cast<hipStream_t>(stream), &took);
             if (rc != ML_OK) return rc;
             if (took) return ML_OK;
@@ -806,6 +826,9 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
         ML_REQUIRE(t == t0, "conv2d: all problems of one launch must use the same tile shape");
         ML_REQUIRE(descs[i].math == descs[0].math, "conv2d: all problems of one launch must use the same math mode");
     }
+    ML_REQUIRE(descs[0].math != ML_MATH_F16S,
+               "conv2d: fp16 storage (ML_MATH_F16S) is implemented for 1x1 stride-1 convs with cout %% 128 == 0, "
+               "span %% 64 == 0, cout <= 1024 only (the ResNeXt bottleneck convs)");
     ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -19,13 +19,34 @@
 
 namespace {
 
+// tensor element type TIO: float, or _Float16 for the fp16-STORAGE mode (BASELINE config 5): 4 channels are then an
+// 8-byte load / store, the halo tile in LDS, the weights and all arithmetic stay fp32, the result is rounded once.
+typedef _Float16 f16x4g __attribute__((ext_vector_type(4)));
+template <class TIO>
+__device__ __forceinline__ f32x4 load4(const TIO *p) {
+    if constexpr (sizeof(TIO) == 4) {
+        return *reinterpret_cast<const f32x4 *>(p);
+    } else {
+        const f16x4g h = *reinterpret_cast<const f16x4g *>(p);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+}
+template <class TIO>
+__device__ __forceinline__ void store4(TIO *p, f32x4 v) {
+    if constexpr (sizeof(TIO) == 4) {
+        *reinterpret_cast<f32x4 *>(p) = v;
+    } else {
+        *reinterpret_cast<f16x4g *>(p) = f16x4g{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+}
+
 constexpr int PS = 80;   // LDS floats per input pixel (64 channels + pad, = 16 mod 64)
 constexpr int CS = 64;   // channels per block
 
-template <int STRIDE, int TH, int TW, int CPG>
+template <int STRIDE, int TH, int TW, int CPG, class TIO>
 __global__ void __launch_bounds__(256)
-gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-                   float *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
+gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+                   TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
                    int tiles_x) {
     constexpr int c = CPG;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
@@ -60,7 +81,7 @@ gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, 
             const int iy = iy0 + py, ix = ix0 + px;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f32x4 *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+                v = load4<TIO>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
             stage[i] = v;
         }
     }
@@ -121,7 +142,7 @@ gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, 
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        *reinterpret_cast<f32x4 *>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc) = r;
+        store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
     }
 }
 
@@ -134,10 +155,10 @@ gconv_mfma4_kernel(const float *__restrict__ in, const float *__restrict__ wgt, 
 // Wave w of the block owns group w of the 64-channel slab and walks the tile's 16-pixel sets.
 constexpr int PS16 = 68;   // LDS floats per pixel: 16 consecutive pixels x 16 B land on 64 distinct banks
 
-template <int STRIDE, int TH, int TW>
+template <int STRIDE, int TH, int TW, class TIO>
 __global__ void __launch_bounds__(256)
-gconv16_kernel(const float *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-               float *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+               TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
@@ -165,7 +186,7 @@ gconv16_kernel(const float *__restrict__ in, const float *__restrict__ wgt, cons
             const int iy = iy0 + py, ix = ix0 + px;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f32x4 *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+                v = load4<TIO>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
             stage[i] = v;
         }
     }
@@ -218,16 +239,16 @@ gconv16_kernel(const float *__restrict__ in, const float *__restrict__ wgt, cons
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        *reinterpret_cast<f32x4 *>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc) = r;
+        store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
     }
 }
 
-template <int STRIDE, int TH, int TW>
-int launch16(const float *in, const float *wgt, const float *bias, float *out, int B, int H, int W, int C, int Ho, int Wo,
+template <int STRIDE, int TH, int TW, class TIO>
+int launch16(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, int H, int W, int C, int Ho, int Wo,
              int pad_t, int pad_l, int act, hipStream_t s) {
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
     constexpr int LDS_BYTES = THIN * TWIN * PS16 * 4;
-    auto kern = gconv16_kernel<STRIDE, TH, TW>;
+    auto kern = gconv16_kernel<STRIDE, TH, TW, TIO>;
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
@@ -237,12 +258,12 @@ int launch16(const float *in, const float *wgt, const float *bias, float *out, i
     return ML_OK;
 }
 
-template <int STRIDE, int TH, int TW, int CPG>
-int launch(const float *in, const float *wgt, const float *bias, float *out, int B, int H, int W, int C, int Ho,
+template <int STRIDE, int TH, int TW, int CPG, class TIO>
+int launch(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, int H, int W, int C, int Ho,
            int Wo, int pad_t, int pad_l, int act, hipStream_t s) {
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
     constexpr int LDS_BYTES = THIN * TWIN * PS * 4;
-    auto kern = gconv_mfma4_kernel<STRIDE, TH, TW, CPG>;
+    auto kern = gconv_mfma4_kernel<STRIDE, TH, TW, CPG, TIO>;
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
@@ -254,9 +275,10 @@ int launch(const float *in, const float *wgt, const float *bias, float *out, int
 
 }  // namespace
 
-extern "C" int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out, int32_t B, int32_t H,
-                               int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad_t,
-                               int32_t pad_l, int32_t act, void *stream) {
+template <class TIO>
+static int gconv3x3_any(const TIO *in, const float *wgt, const float *bias, TIO *out, int32_t B, int32_t H, int32_t W,
+                        int32_t C, int32_t c, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad_t, int32_t pad_l,
+                        int32_t act, void *stream) {
     ML_REQUIRE(in && wgt && out, "gconv3x3: null pointer");
     ML_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "gconv3x3: bad dims");
     ML_REQUIRE(C > 0 && C % CS == 0 && C / CS < 65536, "gconv3x3: channels must be a multiple of %d", CS);
@@ -270,12 +292,25 @@ extern "C" int ml_gconv3x3_f32(const float *in, const float *wgt, const float *b
     hipStream_t s = (hipStream_t)stream;
 #define GC_ARGS in, wgt, bias, out, B, H, W, C, Ho, Wo, pad_t, pad_l, act, s
     if (stride == 1) {
-        if (c == 4) return launch<1, 8, 8, 4>(GC_ARGS);
-        if (c == 8) return launch<1, 8, 8, 8>(GC_ARGS);
-        return launch16<1, 8, 8>(GC_ARGS);
+        if (c == 4) return launch<1, 8, 8, 4, TIO>(GC_ARGS);
+        if (c == 8) return launch<1, 8, 8, 8, TIO>(GC_ARGS);
+        return launch16<1, 8, 8, TIO>(GC_ARGS);
     }
-    if (c == 4) return launch<2, 4, 8, 4>(GC_ARGS);
-    if (c == 8) return launch<2, 4, 8, 8>(GC_ARGS);
-    return launch16<2, 4, 8>(GC_ARGS);
+    if (c == 4) return launch<2, 4, 8, 4, TIO>(GC_ARGS);
+    if (c == 8) return launch<2, 4, 8, 8, TIO>(GC_ARGS);
+    return launch16<2, 4, 8, TIO>(GC_ARGS);
 #undef GC_ARGS
+}
+
+extern "C" int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float *out, int32_t B, int32_t H,
+                               int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad_t,
+                               int32_t pad_l, int32_t act, void *stream) {
+    return gconv3x3_any<float>(in, wgt, bias, out, B, H, W, C, c, Ho, Wo, stride, pad_t, pad_l, act, stream);
+}
+
+extern "C" int ml_gconv3x3_f16(const void *in, const float *wgt, const float *bias, void *out, int32_t B, int32_t H,
+                               int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad_t,
+                               int32_t pad_l, int32_t act, void *stream) {
+    return gconv3x3_any<_Float16>(reinterpret_cast<const _Float16 *>(in), wgt, bias, reinterpret_cast<_Float16 *>(out), B, H,
+                                  W, C, c, Ho, Wo, stride, pad_t, pad_l, act, stream);
 }

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
         ("res_cstride", C.c_int32), ("res_coff", C.c_int32),
         ("act", C.c_int32), ("group_cin_step", C.c_int32), ("shuffle2x2", C.c_int32),
-        ("tile", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32),
+        ("tile", C.c_int32), ("math", C.c_int32), ("out_f16", C.c_int32),
         ("out_bstride", C.c_int64),
     ]
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "ml_conv2d_workspace_bytes": (_i64, []),
     "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
     "ml_gconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
+    "ml_gconv3x3_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
+    "ml_maxpool3x3s2_f16": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
+    "ml_subsample2_f16": (C.c_int, [_vp, _vp] + [_i32] * 4 + [_vp]),
+    "ml_cast_f16_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -84,8 +84,10 @@ class ResNeXt50(Layer):
         return out
 
     def call(self, x, wanted=("C3", "C4", "C5"), **kwargs):
+        import torch
+        half = ops.half_storage()            # fp16-storage mode: the body's tensors are IEEE half, taps go out as fp32
         taps = {}
-        x = self.conv1(x)
+        x = self.conv1(x, out_dtype=torch.float16 if half else None)
         taps["C1"] = x
         x = ops.maxpool3x3s2(x, pad=1)                     # pool1_pad + pool1_pool (:351-352)
         last = max(int(t[1]) for t in wanted)
@@ -95,4 +97,6 @@ class ResNeXt50(Layer):
             taps[tap] = x
             if int(tap[1]) >= last:
                 break
+        if half:
+            taps = {k: (ops.cast_h2f(v) if k in wanted else v) for k, v in taps.items()}
         return taps

@@ -66,11 +66,8 @@ class SlicedGroupConv2D(Conv2D):
     def call(self, x, **kwargs):
         if self.dev is None:
             raise RuntimeError(f"layer '{self.name}' has no weights loaded")
-        if self.use_mfma4:
-            return ops.gconv3x3(x, self.wgt4, self.bias4, self.c, stride=self.strides[0], padding=self.padding,
-                                act=_lib.ACT_BY_NAME[self.activation])
-        return ops.conv2d(x, self.dev, stride=self.strides[0], padding=self.padding,
-                          act=_lib.ACT_BY_NAME[self.activation])
+        from ..keras_like import grouped3x3
+        return grouped3x3(self, x)
 
 
 class _Unit:
@@ -155,8 +152,10 @@ class ResNeXt101(Layer):
         return mean.astype(np.float32), div.astype(np.float32), np.asarray(weights["bn_data/beta"], np.float32)
 
     def call(self, x, wanted=("C3", "C4", "C5"), **kwargs):
+        import torch
+        half = ops.half_storage()            # fp16-storage mode: the body's tensors are IEEE half, taps go out as fp32
         taps = {}
-        x = self.conv0(x)
+        x = self.conv0(x, out_dtype=torch.float16 if half else None)
         taps["C1"] = x
         x = ops.maxpool3x3s2(x, pad=1)
         last = max(int(t[1]) for t in wanted)
@@ -166,4 +165,6 @@ class ResNeXt101(Layer):
             taps[tap] = x
             if int(tap[1]) >= last:
                 break
+        if half:
+            taps = {k: (ops.cast_h2f(v) if k in wanted else v) for k, v in taps.items()}
         return taps

@@ -238,12 +238,12 @@ class Conv2D(Layer):
     def _load_own(self, weights, device):
         self.dev = ops.DeviceConv(self.pack(weights), device)
 
-    def call(self, x, residual=None, out=None, out_coff=0, **kwargs):
+    def call(self, x, residual=None, out=None, out_coff=0, out_dtype=None, **kwargs):
         if self.dev is None:
             raise RuntimeError(f"layer '{self.name}' has no weights loaded")
         return ops.conv2d(x, self.dev, stride=self.strides[0], padding=self.padding,
                           dilation=self.dilation_rate[0], act=_lib.ACT_BY_NAME[self.activation],
-                          residual=residual, out=out, out_coff=out_coff)
+                          residual=residual, out=out, out_coff=out_coff, out_dtype=out_dtype)
 
     def get_config(self):
         c = super().get_config()
@@ -316,11 +316,21 @@ class GroupedConv2D(Conv2D):
     def call(self, x, **kwargs):
         if self.dev is None:
             raise RuntimeError(f"layer '{self.name}' has no weights loaded")
-        if self.use_mfma4:
-            return ops.gconv3x3(x, self.wgt4, self.bias4, self.c, stride=self.strides[0], padding=self.padding,
-                                act=_lib.ACT_BY_NAME[self.activation])
-        return ops.conv2d(x, self.dev, stride=self.strides[0], padding=self.padding,
-                          act=_lib.ACT_BY_NAME[self.activation])
+        return grouped3x3(self, x)
+
+
+def grouped3x3(layer, x):
+    """The grouped 3x3 of a ResNeXt block on whichever kernel fits its group width; in the fp16-storage mode (half
+    `x`) the 32-channel groups of the last stage -- a small tensor on the dense kernel -- go through an fp32 copy of
+    the input and come back as half."""
+    import torch
+    act = _lib.ACT_BY_NAME[layer.activation]
+    if layer.use_mfma4:
+        return ops.gconv3x3(x, layer.wgt4, layer.bias4, layer.c, stride=layer.strides[0], padding=layer.padding, act=act)
+    if x.dtype == torch.float16:
+        return ops.conv2d(ops.cast_h2f(x), layer.dev, stride=layer.strides[0], padding=layer.padding, act=act,
+                          out_dtype=torch.float16)
+    return ops.conv2d(x, layer.dev, stride=layer.strides[0], padding=layer.padding, act=act)
 
 
 class DepthwiseConv2D(Layer):

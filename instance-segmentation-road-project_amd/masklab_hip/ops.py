@@ -41,10 +41,13 @@ class _Prof:
 
 
 # Arithmetic of the dense (MFMA) convolutions: "f32" = exact fp32 products (the default; configs 1-4),
-# "f16" = the fp16 MFMA path of BASELINE config 5 (operands rounded to fp16, fp32 accumulation; tensors
-# stay fp32).  Process-wide switch, read when a conv is launched; set it through set_conv_math().
+# "f16" = fp16 MFMA operands (rounded to fp16 on their way into LDS), fp32 accumulation, tensors stay fp32,
+# "f16s" = the fp16 MFMA path of BASELINE config 5 with fp16 STORAGE: the ResNeXt body keeps activations and
+# weights in IEEE half in HBM (the stem writes half, the bottleneck convs / grouped convs / max-pool read and write
+# half, the C3..C5 taps are cast back to fp32), every other conv runs like "f16".
+# Process-wide switch, read when a conv is launched; set it through set_conv_math().
 CONV_MATH = "f32"
-_MATH_CODE = {"f32": 0, "f16": 1}
+_MATH_CODE = {"f32": 0, "f16": 1, "f16s": 1}        # per-launch code of fp32-tensor convs; half tensors select ML_MATH_F16S
 
 
 def set_conv_math(mode):
@@ -56,7 +59,8 @@ def set_conv_math(mode):
 
 def dtype_label():
     """The arithmetic type the dense-conv path computes in (bench.py's `dtype`)."""
-    return {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate, f32 tensors"}[CONV_MATH]
+    return {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate, f32 tensors",
+            "f16s": "f16 MFMA, f32 accumulate, f16 tensors in the backbone body (f32 heads)"}[CONV_MATH]
 
 
 def _stream():
@@ -65,6 +69,11 @@ def _stream():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def half_storage():
+    """True in the "f16s" mode: backbone bodies keep their tensors in IEEE half."""
+    return CONV_MATH == "f16s"
 
 
 def _require_dev(t, name):
@@ -93,13 +102,27 @@ class DeviceConv:
         self.p = packed
         self.wgt = torch.from_numpy(np.ascontiguousarray(packed.wgt)).to(device)
         self.bias = None if packed.bias is None else torch.from_numpy(packed.bias).to(device)
+        self._wgt_h = None
+
+    @property
+    def wgt_h(self):
+        """The packed weights rounded to IEEE half (fp16-storage convs), made on first use."""
+        if self._wgt_h is None:
+            self._wgt_h = torch.from_numpy(np.ascontiguousarray(self.p.wgt.astype(np.float16))).to(self.wgt.device)
+        return self._wgt_h
 
 
 def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, residual=None, out=None,
-               out_coff=0, in_coff=0, out_view=None):
-    """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args)."""
+               out_coff=0, in_coff=0, out_view=None, out_dtype=None):
+    """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args).
+    A float16 `x` selects the fp16-storage kernel (ML_MATH_F16S: half weights, half residual, half output);
+    out_dtype=torch.float16 on an fp32 `x` makes the generic kernel store half (the stem of an fp16-storage body)."""
     p = dc.p
     _require_dev(x, "x")
+    half_in = x.dtype == torch.float16
+    odt = torch.float16 if (half_in or out_dtype == torch.float16) else torch.float32
+    if half_in and (out_view is not None or (residual is not None and residual.dtype != torch.float16)):
+        raise ValueError("conv2d: an fp16-storage conv takes a float16 residual and no out_view")
     B, H, W, Cbuf = x.shape
     if p.cpp_shift != 30:
         if Cbuf != p.cin_buffer:
@@ -122,16 +145,17 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
         d.out_cstride, d.out_coff, d.out_bstride = vcs, 0, vbs
     else:
         if out is None:
-            out = torch.empty((B, oh, ow, co), dtype=torch.float32, device=x.device)
+            out = torch.empty((B, oh, ow, co), dtype=odt, device=x.device)
             out_coff = 0
         else:
             _require_dev(out, "out")
-            if tuple(out.shape[:3]) != (B, oh, ow):
-                raise ValueError(f"conv2d: out buffer {tuple(out.shape)} does not match {(B, oh, ow)}")
+            if tuple(out.shape[:3]) != (B, oh, ow) or out.dtype != odt:
+                raise ValueError(f"conv2d: out buffer {tuple(out.shape)} / {out.dtype} does not match {(B, oh, ow)} / {odt}")
         ret = out
         d.out = out.data_ptr()
         d.out_cstride, d.out_coff, d.out_bstride = out.shape[3], out_coff, 0
-    d.in_, d.wgt, d.bias = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
+    d.in_, d.wgt, d.bias = x.data_ptr(), (dc.wgt_h if half_in else dc.wgt).data_ptr(), \
+        (dc.bias.data_ptr() if dc.bias is not None else None)
     if residual is not None:
         _require_dev(residual, "residual")
         if tuple(residual.shape[:3]) != (B, Ho, Wo):
@@ -144,34 +168,43 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
-    d.math, d.reserved0 = _MATH_CODE[CONV_MATH], 0
+    if half_in:
+        d.math, d.out_f16 = 2, 0                         # ML_MATH_F16S
+    else:
+        d.math, d.out_f16 = _MATH_CODE[CONV_MATH], int(odt == torch.float16)
+        if d.out_f16 and d.math != 1:
+            raise ValueError("conv2d: a half output from fp32 input needs the fp16 MFMA mode (set_conv_math('f16s'))")
     M = B * Ho * Wo
     real_cin = p.span if p.cpp_shift == 30 else 3
-    nbytes = 4 * (B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + M * p.cout + p.cout * p.k_real
-                  + (M * p.cout if residual is not None else 0))
+    es_in, es_out = x.element_size(), (2 if odt == torch.float16 else 4)
+    nbytes = (es_in * B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + es_out * M * p.cout +
+              es_in * p.cout * p.k_real + (es_out * M * p.cout if residual is not None else 0))
     shape = f"M={M} N={p.cout} K={p.KH * p.KW * p.span_pad} k{p.kh_real}x{p.kw_real} s{stride} d{dilation} HxW={H}x{W}"
     return d, ret, (2.0 * M * p.cout * p.k_real, nbytes, shape)
 
 
 def _conv_kernel_name(p):
     return "conv_mfma_128x%d%s%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile),
-                                     "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH == "f16" else "")
+                                     "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH != "f32" else "")
 
 
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
-           residual=None, out=None, out_coff=0, in_coff=0, out_view=None):
+           residual=None, out=None, out_coff=0, in_coff=0, out_view=None, out_dtype=None):
     """ml_conv2d_multi_f32 with one problem (split-K enabled through the shared workspace).
     `x` [B,H,W,Cbuf]; reads channels [in_coff, in_coff+cin).  Writes into
     `out[..., out_coff:out_coff+cout]` when given, else allocates.  `out_view=(tensor, elem_off,
     cstride, bstride)` writes image b's pixels at tensor.data + elem_off + b*bstride with row
     pitch cstride (used to land a level's head directly in the concatenated prediction)."""
     lib = _lib.load()
+    if x.dtype == torch.float16 and stride == 2 and dc.p.kh_real == 1 and dc.p.kw_real == 1:
+        # a strided 1x1 conv on half tensors = the stride-1 kernel on the sampled pixels (ResNext.py:199-203 shortcuts)
+        x, stride = subsample2_h(x), 1
     d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
-                                                in_coff, out_view)
+                                                in_coff, out_view, out_dtype)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
     name = _conv_kernel_name(dc.p)
     if PROFILE is not None and lib.ml_conv2d_uses_pipe(C.byref(d)):
-        name = "conv1x1_pipe"
+        name = "conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe"
     with _Prof(name, flops, nbytes, shape):
         _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret
@@ -208,11 +241,14 @@ def gconv3x3(x, wgt, bias, c, stride=1, padding=((1, 1), (1, 1)), act=_lib.ACT_N
     _require_dev(x, "x")
     B, H, W, Cc = x.shape
     Ho, Wo, pt, pl = resolve_padding(H, W, 3, 3, stride, 1, padding)
-    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-    with _Prof("gconv3x3_mfma4", 2.0 * B * Ho * Wo * Cc * 9 * c, 4 * (x.numel() + out.numel() + wgt.numel()),
+    half = x.dtype == torch.float16
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    fn = lib.ml_gconv3x3_f16 if half else lib.ml_gconv3x3_f32
+    with _Prof("gconv3x3_mfma4_h" if half else "gconv3x3_mfma4", 2.0 * B * Ho * Wo * Cc * 9 * c,
+               x.element_size() * (x.numel() + out.numel()) + 4 * wgt.numel(),
                f"M={B * Ho * Wo} C={Cc} c={c} s{stride} HxW={H}x{W}"):
-        _lib.check(lib.ml_gconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, c, Ho, Wo, stride, pt, pl,
-                                       act, _stream()), "ml_gconv3x3_f32")
+        _lib.check(fn(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, c, Ho, Wo, stride, pt, pl, act, _stream()),
+                   "ml_gconv3x3")
     return out
 
 
@@ -237,10 +273,36 @@ def maxpool3x3s2(x, pad=1):
     B, H, W, Cc = x.shape
     Ho = (H + 2 * pad - 3) // 2 + 1
     Wo = (W + 2 * pad - 3) // 2 + 1
-    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-    with _Prof("maxpool3x3s2", 0, 4 * (x.numel() + out.numel())):
-        _lib.check(lib.ml_maxpool3x3s2_f32(_ptr(x), _ptr(out), B, H, W, Cc, Ho, Wo, pad, pad, _stream()),
-                   "ml_maxpool3x3s2_f32")
+    half = x.dtype == torch.float16
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    fn = lib.ml_maxpool3x3s2_f16 if half else lib.ml_maxpool3x3s2_f32
+    with _Prof("maxpool3x3s2_h" if half else "maxpool3x3s2", 0, x.element_size() * (x.numel() + out.numel())):
+        _lib.check(fn(_ptr(x), _ptr(out), B, H, W, Cc, Ho, Wo, pad, pad, _stream()), "ml_maxpool3x3s2")
+    return out
+
+
+def subsample2_h(x):
+    """ml_subsample2_f16: x[:, ::2, ::2, :] of a float16 NHWC tensor (what a 1x1 stride-2 conv reads)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    if x.dtype != torch.float16:
+        raise RuntimeError("subsample2_h: float16 tensor expected")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, Cc), dtype=torch.float16, device=x.device)
+    with _Prof("subsample2_h", 0, 2 * 2 * out.numel()):
+        _lib.check(lib.ml_subsample2_f16(_ptr(x), _ptr(out), B, H, W, Cc, _stream()), "ml_subsample2_f16")
+    return out
+
+
+def cast_h2f(x):
+    """ml_cast_f16_to_f32: a float16 tensor as float32 (the backbone taps handed to the fp32 heads)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    if x.dtype != torch.float16:
+        raise RuntimeError("cast_h2f: float16 tensor expected")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with _Prof("cast_h2f", 0, 6 * x.numel()):
+        _lib.check(lib.ml_cast_f16_to_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "ml_cast_f16_to_f32")
     return out
 
 

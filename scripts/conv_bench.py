@@ -61,13 +61,46 @@ def ab_pipe(reps):
               f"{mb / m4:6.0f} GB/s | x{m1 / m4:.2f}", flush=True)
 
 
+def half_pipe(reps):
+    """the pipelined 1x1 kernel on fp16 tensors (BASELINE config-5 shapes: 16 x 1280^2 ResNeXt-101): HBM GB/s"""
+    rng = np.random.default_rng(0)
+    ops.set_conv_math("f16s")
+    shapes = [("s1 64->128", 16, 320, 64, 128, False), ("s1 64->256 sc", 16, 320, 64, 256, False),
+              ("s1 128->256 +res", 16, 320, 128, 256, True), ("s1 256->128", 16, 320, 256, 128, False),
+              ("s2 256->512 +res", 16, 160, 256, 512, True), ("s2 512->256", 16, 160, 512, 256, False),
+              ("s3 512->1024 +res", 16, 80, 512, 1024, True), ("s3 1024->512", 16, 80, 1024, 512, False),
+              ("s4 1024->2048 +res", 16, 40, 1024, 2048, True), ("s4 2048->1024", 16, 40, 2048, 1024, False)]
+    for label, B, S, cin, cout, res in shapes:
+        x = torch.from_numpy(rng.normal(size=(B, S, S, cin)).astype(np.float16)).cuda()
+        w = rng.normal(size=(1, 1, cin, cout)).astype(np.float32) * 0.05
+        dc = ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32)), "cuda")
+        r = torch.from_numpy(rng.normal(size=(B, S, S, cout)).astype(np.float16)).cuda() if res else None
+        out = torch.empty((B, S, S, cout), dtype=torch.float16, device="cuda")
+        for _ in range(3):
+            ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        gf = 2.0 * out.numel() * cin / 1e9
+        mb = 2 * (x.numel() + out.numel() * (2 if res else 1)) / 1e6
+        print(f"{label:24s} {1e3 * ms:8.1f} us {gf / ms:7.1f} TF/s {mb / ms:7.0f} GB/s ({mb / ms / 80:.0f} % of 8 TB/s)", flush=True)
+    ops.set_conv_math("f32")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--ab-pipe", action="store_true")
+    ap.add_argument("--half-pipe", action="store_true")
     args = ap.parse_args()
     if args.ab_pipe:
         return ab_pipe(args.reps)
+    if args.half_pipe:
+        return half_pipe(args.reps)
     rng = np.random.default_rng(0)
     tot_ms, tot_gf = 0.0, 0.0
     for label, B, H, W, cin, cout, k, stride, res in SHAPES:
