@@ -164,6 +164,24 @@ int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const f
                            int32_t out_cstride, int32_t out_coff, /* y view: channels of the buffer / first channel; (C,0) = dense */
                            void *workspace, void *stream);
 
+/* Several independent GroupNormalizations in one launch pair (the five pyramid levels of a tower depth,
+ * detection.py:124,194; the three RoI levels of the mask head, instance.py:192): the few-thousand-float problems of
+ * the coarse levels ride along instead of being ~10 us launches of their own.  Same arithmetic per problem.
+ * Every problem: 16-byte aligned tensors, HWC/G and C multiples of 4.  workspace_bytes >= the sum over the problems of
+ * ml_groupnorm_workspace_bytes(N, G).                                                                          */
+typedef struct ml_gn_desc {
+    const float *x;
+    float *y;
+    const float *gamma, *beta;     /* [C] or NULL                                   */
+    int64_t HWC;                   /* floats per sample                             */
+    int32_t N, C, G, relu;
+    int32_t out_cstride, out_coff; /* y view, as in ml_groupnorm_chunk_f32          */
+    float eps;
+    int32_t reserved;
+} ml_gn_desc;
+#define ML_GN_MAX_PROBLEMS 8
+int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------- resampling / reductions
  * tf.compat.v1.image.resize_bilinear(align_corners=True) (engine/layers/misc.py:306), with the
  * FPN `Add` (detection.py:58-60) or a concat-slice write (semantic.py:154,227) fused.        */

@@ -40,7 +40,12 @@ constexpr int ROWB = 128;                          // bytes of K per staged row 
 constexpr int BUFB = (BM + BN) * ROWB;             // bytes per staging buffer (32 KB)
 constexpr int SCR_LD = 36;                         // floats per row of the transposition scratch (16-byte aligned rows)
 constexpr int SCRB = 16 * SCR_LD * 4;              // bytes of scratch per wave
-constexpr int PIPE_LDS_BYTES = 2 * BUFB + 4 * SCRB;    // + 4 B per output channel for the bias: two blocks per CU
+// LDS per block = NSTAGE staging buffers + 4 scratches + 4 B per bias channel of the block's N tiles.  NSTAGE = 2
+// (78 KB, two blocks per CU) is what runs: for fp16 tensors a 4-deep ring with one block per CU was measured SLOWER
+// (gpurun_out/r02i_half.log vs r02g_ab.log: 267 vs 232 us at 512 -> 1024 + residual) -- the fp16 chunk is 16 MFMAs of 32
+// cycles and the 8 LDS-direct loads beside it cost more issue time than that, which a second resident block hides and a
+// deeper ring does not.
+constexpr int pipe_lds_bytes(int nstage) { return nstage * BUFB + 4 * SCRB; }
 constexpr int PIPE_MAX_NBG = 8;                    // N tiles one block walks (its slice of the bias lives in LDS)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -188,7 +193,7 @@ __device__ __forceinline__ void finish_piece(const f32x16 (&acc)[2][2], const Pi
 //                         [p < NPC, residual] issue the residual load(s) of piece p (consumed LEAD pieces later).
 // Vector-memory issue order of a FIRST chunk, on which the hand-counted waits rely (sched_barrier pins it):
 //   8 staging loads, then per piece: stores(q) before loads(p).
-template <class T, bool FIRST, bool HAS_RES, int NB4>
+template <class T, bool FIRST, bool HAS_RES, int NB4>   // (the staging depth only shows in which buffer `wr` is)
 __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2][2], const PipeState &S, const char *rd,
                                            char *wr, char *scratch, __amdgpu_buffer_rsrc_t ra_nx,
                                            __amdgpu_buffer_rsrc_t rb_nx, int soff_nx, __amdgpu_buffer_rsrc_t ro_prev,
@@ -277,8 +282,8 @@ __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2]
     });
 }
 
-template <class T, bool HAS_RES>
-__global__ void __launch_bounds__(256, 2)
+template <class T, bool HAS_RES, int NSTAGE>
+__global__ void __launch_bounds__(256, NSTAGE == 2 ? 2 : 1)
 conv1x1_pipe_kernel(const PipeArgs A) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int ES = sizeof(T);
@@ -342,8 +347,8 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     // ever works on ONE group of NBG N tiles (unit u -> group u & gmask, and u advances by the grid size, a multiple
     // of the group count).  The bias is read with ds_read at a tile switch: a global load there would be waited for
     // with vmcnt(0) while LDS-direct loads are in flight.
-    char *scratch = lds + 2 * BUFB + S.wave_u * SCRB;
-    float *lds_bias = reinterpret_cast<float *>(lds + 2 * BUFB + 4 * SCRB);
+    char *scratch = lds + NSTAGE * BUFB + S.wave_u * SCRB;
+    float *lds_bias = reinterpret_cast<float *>(lds + NSTAGE * BUFB + 4 * SCRB);
     const int nt0 = first_nt((int)blockIdx.x);
     for (int i = tid; i < A.NBG * BN; i += 256) lds_bias[i] = A.bias ? A.bias[nt0 * BN + i] : 0.f;
     __syncthreads();
@@ -367,17 +372,19 @@ conv1x1_pipe_kernel(const PipeArgs A) {
 #pragma unroll
         for (int k = 0; k < NB4; ++k) bias_prev[ni][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_bias(cur, bias_cur);
-    // ---- prologue: first chunk of the first tile
-    {
+    // ---- prologue: the first NSTAGE - 1 chunks of the block's stream (they may already cross into the next tile)
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st) {
         const __amdgpu_buffer_rsrc_t ra = res_a(nx), rb = res_b(nx);
+        const int soff = kc_nx * ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(ra, lds + (32 * i + 8 * S.wave_u) * ROWB, S.a_voff[i], 0);
+        for (int i = 0; i < 4; ++i) lds_dma16(ra, lds + st * BUFB + (32 * i + 8 * S.wave_u) * ROWB, S.a_voff[i], soff);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(rb, lds + (BM + 32 * i + 8 * S.wave_u) * ROWB, S.b_voff[i], 0);
-        kc_nx = 1;
+        for (int i = 0; i < 4; ++i) lds_dma16(rb, lds + st * BUFB + (BM + 32 * i + 8 * S.wave_u) * ROWB, S.b_voff[i], soff);
+        ++kc_nx;
         if (kc_nx == nk) { kc_nx = 0; nx = advance(nx); }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2)) : "memory");      // chunk 0 has landed
     __builtin_amdgcn_s_barrier();
 
     Cursor prev = {A.units, 0};           // nothing to store yet: empty resource
@@ -393,7 +400,7 @@ conv1x1_pipe_kernel(const PipeArgs A) {
             const __amdgpu_buffer_rsrc_t ra_nx = res_a(nx), rb_nx = res_b(nx);
             const int soff_nx = kc_nx * ROWB;
             const char *rd = lds + buf * BUFB;
-            char *wr = lds + (buf ^ 1) * BUFB;
+            char *wr = lds + (buf == 0 ? NSTAGE - 1 : buf - 1) * BUFB;     // the buffer the previous chunk was read from
             const bool first = kc == 0;
             // (wave-uniform branch: two instantiations of the chunk per accumulator role)
             if (first) pipe_chunk<T, true, HAS_RES, NB4>(acc, oth, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ro_prev, bias_prev, rr_prev);
@@ -401,10 +408,14 @@ conv1x1_pipe_kernel(const PipeArgs A) {
             // advance the staging cursor
             ++kc_nx;
             if (kc_nx == nk) { kc_nx = 0; nx = advance(nx); }
-            buf ^= 1;
-            // FIRST chunks end with the piece stores (16 / 8) younger than the 8 staging loads: wait for the loads only
-            if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F32 ? 16 : 8) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+            // The NEXT chunk's staging loads must have landed.  Younger than them are the loads of the NSTAGE - 2
+            // chunks after it and the piece stores (16 / 8) of a first chunk among the last NSTAGE - 1 chunks (its
+            // residual loads were waited for inside it): vector-memory operations complete in order, so allowing
+            // exactly that many to stay outstanding waits for nothing else.  (Short tiles with more than one first
+            // chunk in that window only make the wait stricter.)
+            if (kc <= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2) + (F32 ? 16 : 8)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         prev = cur;
@@ -443,13 +454,14 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     }
 }
 
-template <class T, bool HAS_RES>
-int launch_pipe(const PipeArgs &A, int lds_bytes, hipStream_t s) {
-    auto kern = conv1x1_pipe_kernel<T, HAS_RES>;
+template <class T, bool HAS_RES, int NSTAGE>
+int launch_pipe(const PipeArgs &A, hipStream_t s) {
+    auto kern = conv1x1_pipe_kernel<T, HAS_RES, NSTAGE>;
     static std::atomic<unsigned long long> ok{0};          // per kernel instantiation, one bit per device
-    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), PIPE_LDS_BYTES + 4 * PIPE_MAX_NBG * BN, ok, "conv1x1_pipe"))
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), pipe_lds_bytes(NSTAGE) + 4 * PIPE_MAX_NBG * BN, ok,
+                                       "conv1x1_pipe"))
         return rc;
-    hipLaunchKernelGGL(kern, dim3(A.grid), dim3(256), lds_bytes, s, A);
+    hipLaunchKernelGGL(kern, dim3(A.grid), dim3(256), pipe_lds_bytes(NSTAGE) + 4 * A.NBG * BN, s, A);
     ML_CHECK_LAUNCH("conv1x1_pipe");
     return ML_OK;
 }
@@ -489,24 +501,24 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     A.in_cs = d.in_cstride; A.in_coff = d.in_coff; A.out_cs = d.out_cstride; A.out_coff = d.out_coff;
     A.panels = (int)((M + BM - 1) / BM);
     A.NB = d.cout / BN;
-    // enough work units to fill 2 blocks on each of the 256 CUs, and at most PIPE_MAX_NBG N tiles per block: split a
+    // enough work units to fill every resident block (2 per CU), and at most PIPE_MAX_NBG N tiles per block: split a
     // panel's N tiles into 2^gshift groups
+    const int resident = 512;
     A.gshift = 0;
-    while (((long long)A.panels << A.gshift < 512 || (A.NB >> A.gshift) > PIPE_MAX_NBG) && (A.NB >> A.gshift) % 2 == 0 &&
+    while (((long long)A.panels << A.gshift < resident || (A.NB >> A.gshift) > PIPE_MAX_NBG) && (A.NB >> A.gshift) % 2 == 0 &&
            (A.NB >> A.gshift) > 1)
         ++A.gshift;
     A.NBG = A.NB >> A.gshift;
     if (A.NBG > PIPE_MAX_NBG) return ML_OK;              // (an odd tile count above the limit: the generic kernel)
     A.units = A.panels << A.gshift;
-    A.grid = A.units < 512 ? A.units : 512;
+    A.grid = A.units < resident ? A.units : resident;
     A.lo = d.act == ML_ACT_NONE ? -3.402823466e38f : 0.f;
     A.hi = d.act == ML_ACT_RELU6 ? 6.f : 3.402823466e38f;
-    const int lds_bytes = PIPE_LDS_BYTES + 4 * A.NBG * BN;
     int rc;
     if (d.math == ML_MATH_F16S)
-        rc = d.residual ? launch_pipe<_Float16, true>(A, lds_bytes, s) : launch_pipe<_Float16, false>(A, lds_bytes, s);
+        rc = d.residual ? launch_pipe<_Float16, true, 2>(A, s) : launch_pipe<_Float16, false, 2>(A, s);
     else
-        rc = d.residual ? launch_pipe<float, true>(A, lds_bytes, s) : launch_pipe<float, false>(A, lds_bytes, s);
+        rc = d.residual ? launch_pipe<float, true, 2>(A, s) : launch_pipe<float, false, 2>(A, s);
     if (rc != ML_OK) return rc;
     *eligible = 1;
     return ML_OK;

@@ -40,6 +40,20 @@ __device__ __forceinline__ void store4(TIO *p, f32x4 v) {
     }
 }
 
+// staging: every thread moves 16 bytes per load -- 4 fp32 or 8 fp16 channels of one halo pixel
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+template <class TIO> struct Stage16 { typedef f32x4 type; };
+template <> struct Stage16<_Float16> { typedef f16x8g type; };
+template <class TIO>
+__device__ __forceinline__ void stage_to_lds(float *dst, const typename Stage16<TIO>::type &v) {
+    if constexpr (sizeof(TIO) == 4) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+    } else {
+        *reinterpret_cast<f32x4 *>(dst) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    }
+}
+
 constexpr int PS = 80;   // LDS floats per input pixel (64 channels + pad, = 16 mod 64)
 constexpr int CS = 64;   // channels per block
 
@@ -52,7 +66,10 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
-    constexpr int NLD = (NPIX + 15) / 16;       // staging float4 loads per thread
+    constexpr int CPT = 16 / (int)sizeof(TIO);  // channels per staging load: 4 (fp32) / 8 (fp16)
+    constexpr int TPP = CS / CPT;               // threads per halo pixel
+    constexpr int PPP = 256 / TPP;              // pixels per pass of the block
+    constexpr int NLD = (NPIX + PPP - 1) / PPP; // staging 16-byte loads per thread
     constexpr int QUADS = TH * TW / 4;          // 4-pixel quads (along x) per tile
     constexpr int QPW = QUADS / 4;              // quads per wave
     constexpr int WV = 9 * c / 4;               // weight float4 per lane
@@ -71,17 +88,17 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
 
     // ---- all global loads of the block are issued up front (memory-level parallelism): the halo
     //      tile (16 float4 per pixel, zero outside the image) and this lane's 9*c weights
-    f32x4 stage[NLD];
+    typename Stage16<TIO>::type stage[NLD];
     {
-        const int c4 = (tid & 15) * 4;
+        const int cN = (tid % TPP) * CPT;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = (tid >> 4) + 16 * i;
+            const int p = tid / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            typename Stage16<TIO>::type v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = load4<TIO>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
             stage[i] = v;
         }
     }
@@ -92,11 +109,11 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
         for (int i = 0; i < WV; ++i) wv[i] = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
     }
     {
-        const int c4 = (tid & 15) * 4;
+        const int cN = (tid % TPP) * CPT;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = (tid >> 4) + 16 * i;
-            if (p < NPIX) *reinterpret_cast<f32x4 *>(tile + p * PS + c4) = stage[i];
+            const int p = tid / TPP + PPP * i;
+            if (p < NPIX) stage_to_lds<TIO>(tile + p * PS + cN, stage[i]);
         }
     }
     __syncthreads();
@@ -162,7 +179,10 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
-    constexpr int NLD = (NPIX + 15) / 16;
+    constexpr int CPT = 16 / (int)sizeof(TIO);
+    constexpr int TPP = CS / CPT;
+    constexpr int PPP = 256 / TPP;
+    constexpr int NLD = (NPIX + PPP - 1) / PPP;
     constexpr int SETS = TH * TW / 16;          // 16-pixel sets per tile: two output rows of 8
     static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
     extern __shared__ __align__(16) float tile[];   // [NPIX][PS16]
@@ -176,17 +196,17 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
 
-    f32x4 stage[NLD];
+    typename Stage16<TIO>::type stage[NLD];
     {
-        const int c4 = (tid & 15) * 4;
+        const int cN = (tid % TPP) * CPT;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = (tid >> 4) + 16 * i;
+            const int p = tid / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            typename Stage16<TIO>::type v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = load4<TIO>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + c4);
+                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
             stage[i] = v;
         }
     }
@@ -198,11 +218,11 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
         for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(wrow + t * 16);
     }
     {
-        const int c4 = (tid & 15) * 4;
+        const int cN = (tid % TPP) * CPT;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = (tid >> 4) + 16 * i;
-            if (p < NPIX) *reinterpret_cast<f32x4 *>(tile + p * PS16 + c4) = stage[i];
+            const int p = tid / TPP + PPP * i;
+            if (p < NPIX) stage_to_lds<TIO>(tile + p * PS16 + cN, stage[i]);
         }
     }
     __syncthreads();

@@ -35,11 +35,9 @@ static GnPlan gn_plan(long long L, int NG) {
     return {S, slice};
 }
 
-template <bool VEC4>
-__global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, long long L, long long slice,
-                                int S) {
-    const int ng = blockIdx.y;
-    const int s = blockIdx.x;
+template <bool VEC4 = true>
+__device__ __forceinline__ void gn_stats_body(const float *__restrict__ x, double *__restrict__ ws, long long L,
+                                              long long slice, int S, int ng, int s) {
     const float *p = x + (long long)ng * L;
     const long long lo = (long long)s * slice;
     const long long hi = min(lo + slice, L);
@@ -77,11 +75,16 @@ __global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict_
 }
 
 template <bool VEC4>
-__global__ void gn_apply_kernel(const float *x, float *y, const float *__restrict__ gamma,
-                                const float *__restrict__ beta, const double *__restrict__ ws, long long L,
-                                long long slice, int S, int C, int G, float eps, int relu, int out_cs, int out_co) {
-    const int ng = blockIdx.y;
-    const int s = blockIdx.x;
+__global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, long long L, long long slice,
+                                int S) {
+    gn_stats_body<VEC4>(x, ws, L, slice, S, blockIdx.y, blockIdx.x);
+}
+
+template <bool VEC4 = true>
+__device__ __forceinline__ void gn_apply_body(const float *x, float *y, const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, const double *__restrict__ ws, long long L,
+                                              long long slice, int S, int C, int G, float eps, int relu, int out_cs,
+                                              int out_co, int ng, int s) {
     const int g = ng % G;
     const int cg = C / G;
     double sum = 0, sq = 0;
@@ -165,6 +168,13 @@ __global__ void gn_apply_kernel(const float *x, float *y, const float *__restric
     }
 }
 
+template <bool VEC4>
+__global__ void gn_apply_kernel(const float *x, float *y, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, const double *__restrict__ ws, long long L,
+                                long long slice, int S, int C, int G, float eps, int relu, int out_cs, int out_co) {
+    gn_apply_body<VEC4>(x, y, gamma, beta, ws, L, slice, S, C, G, eps, relu, out_cs, out_co, blockIdx.y, blockIdx.x);
+}
+
 // ---- one-pass form: the chunk lives in registers.  Block (TPB threads) = one (sample, chunk).
 template <int TPB>
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -181,11 +191,10 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 }
 
 template <int TPB, int VPT>
-__global__ void __launch_bounds__(TPB)
-gn_onepass_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
-                  const float *__restrict__ beta, int L, int C, int G, float eps, int relu, int out_cs, int out_co) {
+__device__ __forceinline__ void gn_onepass_body(const float *__restrict__ x, float *__restrict__ y,
+                                                const float *__restrict__ gamma, const float *__restrict__ beta, int L,
+                                                int C, int G, float eps, int relu, int out_cs, int out_co, int ng) {
     __shared__ double red[TPB / 64];
-    const int ng = blockIdx.x;
     const int g = ng % G;
     const int cg = C / G;
     const float *p = x + (long long)ng * L;
@@ -239,16 +248,137 @@ gn_onepass_kernel(const float *__restrict__ x, float *__restrict__ y, const floa
 }
 
 template <int TPB, int VPT>
+__global__ void __launch_bounds__(TPB)
+gn_onepass_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
+                  const float *__restrict__ beta, int L, int C, int G, float eps, int relu, int out_cs, int out_co) {
+    gn_onepass_body<TPB, VPT>(x, y, gamma, beta, L, C, G, eps, relu, out_cs, out_co, blockIdx.x);
+}
+
+template <int TPB, int VPT>
 void launch_onepass(const float *x, float *y, const float *gamma, const float *beta, int NG, int L, int C, int G,
                     float eps, int relu, int out_cs, int out_co, hipStream_t s) {
     hipLaunchKernelGGL((gn_onepass_kernel<TPB, VPT>), dim3(NG), dim3(TPB), 0, s, x, y, gamma, beta, L, C, G, eps, relu,
                        out_cs, out_co);
 }
 
+
+// ------------------------------------------------------------------ several problems in one launch pair
+// The un-shared towers normalise five pyramid levels (and the mask head three RoI levels) one after the other:
+// the two coarsest levels are a few thousand floats each, i.e. a ~10 us launch apiece behind the 46 us P3 launch.
+// ml_groupnorm_multi_f32 runs all of them as (1) one statistics launch over the problems with large chunks and
+// (2) one launch that applies those AND normalises the small-chunk problems in their register-resident one-pass
+// form.  Same per-problem arithmetic as the single-problem kernels (bit-identical results).
+struct GnProb {
+    const float *x;
+    float *y;
+    const float *gamma, *beta;
+    double *ws;               // partials of this problem (two-pass only)
+    long long L, slice;
+    int NG, S, C, G, relu, out_cs, out_co, onepass_vpt;   // onepass_vpt: 0 = two-pass, else float4 per thread
+    float eps;
+};
+struct GnMulti {
+    int n;
+    int start[ML_GN_MAX_PROBLEMS + 1];
+    GnProb p[ML_GN_MAX_PROBLEMS];
+};
+
+__global__ void __launch_bounds__(GN_TPB)
+gn_multi_stats_kernel(const GnMulti A) {
+    int pi = 0;
+    while (pi + 1 < A.n && (int)blockIdx.x >= A.start[pi + 1]) ++pi;
+    const GnProb &P = A.p[pi];
+    const int id = blockIdx.x - A.start[pi];
+    gn_stats_body(P.x, P.ws, P.L, P.slice, P.S, id / P.S, id % P.S);
+}
+
+__global__ void __launch_bounds__(GN_TPB)
+gn_multi_apply_kernel(const GnMulti A) {
+    int pi = 0;
+    while (pi + 1 < A.n && (int)blockIdx.x >= A.start[pi + 1]) ++pi;
+    const GnProb &P = A.p[pi];
+    const int id = blockIdx.x - A.start[pi];
+    if (P.onepass_vpt == 0) {
+        gn_apply_body(P.x, P.y, P.gamma, P.beta, P.ws, P.L, P.slice, P.S, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co,
+                      id / P.S, id % P.S);
+    } else if (P.onepass_vpt == 1) {
+        gn_onepass_body<GN_TPB, 1>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+    } else if (P.onepass_vpt == 2) {
+        gn_onepass_body<GN_TPB, 2>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+    } else {
+        gn_onepass_body<GN_TPB, 4>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t ml_groupnorm_workspace_bytes(int32_t N, int32_t G) {
     return (int64_t)N * G * GN_MAX_SPLIT * 2 * (int64_t)sizeof(double);
+}
+
+static int gn_validate(const float *x, float *y, int32_t N, int64_t HWC, int32_t C, int32_t G, int32_t out_cstride,
+                       int32_t out_coff) {
+    ML_REQUIRE(x && y, "groupnorm: null pointer");
+    ML_REQUIRE(N > 0 && HWC > 0 && C > 0 && G > 0, "groupnorm: bad dims");
+    ML_REQUIRE(C >= G, "groupnorm: Number of groups (%d) cannot be more than the number of channels (%d).", G, C);
+    ML_REQUIRE(C % G == 0, "groupnorm: Number of groups (%d) must be a multiple of the number of channels (%d).", G, C);
+    ML_REQUIRE(HWC % C == 0 && HWC % G == 0, "groupnorm: H*W*C (%lld) must be divisible by C and by G", (long long)HWC);
+    ML_REQUIRE((long long)N * G < 65536, "groupnorm: N*G too large for grid.y");
+    ML_REQUIRE(out_cstride >= C && out_coff >= 0 && out_coff + C <= out_cstride, "groupnorm: bad output slice");
+    ML_REQUIRE(out_cstride == C ? out_coff == 0 : true, "groupnorm: dense output must have out_coff 0");
+    return ML_OK;
+}
+
+extern "C" int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
+                                      void *stream) {
+    ML_REQUIRE(descs && n >= 1 && n <= ML_GN_MAX_PROBLEMS && workspace, "groupnorm_multi: need 1..%d problems and a workspace",
+               ML_GN_MAX_PROBLEMS);
+    GnMulti st, ap;
+    st.n = 0;
+    ap.n = n;
+    long long sb = 0, ab = 0, ws_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const ml_gn_desc &d = descs[i];
+        if (int rc = gn_validate(d.x, d.y, d.N, d.HWC, d.C, d.G, d.out_cstride, d.out_coff)) return rc;
+        const long long L = d.HWC / d.G;
+        const bool vec4 = (L % 4 == 0) && (d.C % 4 == 0) && (d.out_cstride % 4 == 0) && (d.out_coff % 4 == 0) &&
+                          ml_aligned16(d.x) && ml_aligned16(d.y);
+        ML_REQUIRE(vec4, "groupnorm_multi: problem %d needs 16-byte aligned tensors and chunk / channel counts that are "
+                   "multiples of 4 (use ml_groupnorm_chunk_f32 otherwise)", i);
+        GnProb P;
+        P.x = d.x; P.y = d.y; P.gamma = d.gamma; P.beta = d.beta;
+        P.L = L; P.NG = d.N * d.G; P.C = d.C; P.G = d.G; P.relu = d.relu; P.out_cs = d.out_cstride; P.out_co = d.out_coff;
+        P.eps = d.eps;
+        P.ws = nullptr; P.S = 1; P.slice = L; P.onepass_vpt = 0;
+        if (L <= GN_ONEPASS_MAX) {
+            const int v4 = (int)((L + 3) / 4);
+            P.onepass_vpt = v4 <= 256 ? 1 : (v4 <= 512 ? 2 : 4);
+            ap.start[i] = (int)ab;
+            ab += P.NG;
+        } else {
+            const GnPlan plan = gn_plan(L, P.NG);
+            P.S = plan.S; P.slice = plan.slice;
+            const long long bytes = (long long)P.NG * P.S * 2 * (long long)sizeof(double);
+            ML_REQUIRE(ws_off + bytes <= workspace_bytes, "groupnorm_multi: workspace too small (%lld bytes needed so far)",
+                       ws_off + bytes);
+            P.ws = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + ws_off);
+            ws_off += (bytes + 255) / 256 * 256;
+            st.start[st.n] = (int)sb;
+            st.p[st.n++] = P;
+            sb += (long long)P.NG * P.S;
+            ap.start[i] = (int)ab;
+            ab += (long long)P.NG * P.S;
+        }
+        ap.p[i] = P;
+        ML_REQUIRE(ab < (1ll << 31) && sb < (1ll << 31), "groupnorm_multi: grid too large");
+    }
+    st.start[st.n] = (int)sb;
+    ap.start[n] = (int)ab;
+    hipStream_t s = (hipStream_t)stream;
+    if (st.n > 0) hipLaunchKernelGGL(gn_multi_stats_kernel, dim3((unsigned)sb), dim3(GN_TPB), 0, s, st);
+    hipLaunchKernelGGL(gn_multi_apply_kernel, dim3((unsigned)ab), dim3(GN_TPB), 0, s, ap);
+    ML_CHECK_LAUNCH("groupnorm_multi");
+    return ML_OK;
 }
 
 extern "C" int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const float *beta, int32_t N,

@@ -36,6 +36,14 @@ class ConvDesc(C.Structure):
     ]
 
 
+class GnDesc(C.Structure):
+    """Mirror of `ml_gn_desc` (include/masklab_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("HWC", C.c_int64), ("N", C.c_int32), ("C", C.c_int32), ("G", C.c_int32), ("relu", C.c_int32),
+                ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32)]
+
+
+GN_MAX_PROBLEMS = 8
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/masklab_hip.h declares
@@ -58,6 +66,7 @@ SIGNATURES = {
     "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), _vp]),
     "ml_groupnorm_workspace_bytes": (_i64, [_i32, _i32]),
+    "ml_groupnorm_multi_f32": (C.c_int, [C.POINTER(GnDesc), _i32, _vp, _i64, _vp]),
     "ml_groupnorm_chunk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
     "ml_resize_bilinear_ac_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 12 + [_vp]),
     "ml_global_mean_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),

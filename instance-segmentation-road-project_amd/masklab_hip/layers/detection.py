@@ -105,7 +105,7 @@ class _TowerMixin:
             xs = ops.conv2d_multi([dict(x=x, dc=c.dev, stride=c.strides[0], padding=c.padding,
                                         dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation])
                                    for c, x in zip(convs, xs)])
-            xs = [b[2 * i + 1](x, inplace=True) for b, x in zip(blocks, xs)]
+            xs = GroupNormalization.call_multi([b[2 * i + 1] for b in blocks], xs, inplace=True)
         return xs
 
     @staticmethod

@@ -67,6 +67,23 @@ class GroupNormalization(Layer):
         return ops.groupnorm_chunk(inputs, self.gamma, self.beta, self.groups, self.epsilon, relu=fuse_relu,
                                    out=inputs if inplace else None)
 
+    @staticmethod
+    def call_multi(layers, inputs, inplace=False):
+        """The same layers applied to their own inputs in ONE launch pair (the un-shared towers normalise five pyramid
+        levels at every depth, reference engine/layers/detection.py:124,194): results identical to calling each."""
+        probs = []
+        for layer, x in zip(layers, inputs):
+            if not layer.built:
+                layer.build(tuple(x.shape))
+            if (layer.scale and layer.gamma is None) or (layer.center and layer.beta is None):
+                raise RuntimeError(f"layer '{layer.name}' has no weights loaded")
+            hwc = x.numel() // x.shape[0]
+            if (hwc // layer.groups) % 4 or x.shape[-1] % 4:        # the multi launch takes float4-able problems only
+                return [l(x_, inplace=inplace) for l, x_ in zip(layers, inputs)]
+            probs.append(dict(x=x, gamma=layer.gamma, beta=layer.beta, groups=layer.groups, eps=layer.epsilon,
+                              out=x if inplace else None))
+        return ops.groupnorm_chunk_multi(probs)
+
     def get_config(self):
         config = {
             'groups': self.groups, 'axis': self.axis, 'epsilon': self.epsilon, 'center': self.center,

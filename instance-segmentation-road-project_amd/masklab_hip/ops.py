@@ -351,6 +351,46 @@ def groupnorm_chunk(x, gamma, beta, groups, eps=1e-5, relu=False, out=None, out_
     return out
 
 
+def groupnorm_chunk_multi(problems):
+    """ml_groupnorm_multi_f32: several independent GroupNormalizations in one launch pair.
+    problems: list of dicts (x, gamma, beta, groups, eps, relu=False, out=None, out_coff=0) -> list of outputs."""
+    lib = _lib.load()
+    n = len(problems)
+    if n == 0:
+        return []
+    if n > _lib.GN_MAX_PROBLEMS:
+        return groupnorm_chunk_multi(problems[:_lib.GN_MAX_PROBLEMS]) + groupnorm_chunk_multi(problems[_lib.GN_MAX_PROBLEMS:])
+    arr = (_lib.GnDesc * n)()
+    outs, nbytes, ws_bytes = [], 0, 0
+    for i, pr in enumerate(problems):
+        x = pr["x"]
+        _require_dev(x, "x")
+        out = pr.get("out")
+        if out is None:
+            out = torch.empty_like(x)
+        _require_dev(out, "out")
+        N, Cc = x.shape[0], x.shape[-1]
+        out_cs, out_coff = out.shape[-1], pr.get("out_coff", 0)
+        if out_cs == Cc:
+            if out.numel() != x.numel() or out_coff != 0:
+                raise ValueError("groupnorm: dense output must match the input size")
+        elif tuple(out.shape[:-1]) != tuple(x.shape[:-1]):
+            raise ValueError("groupnorm: concat buffer spatial shape mismatch")
+        d = arr[i]
+        d.x, d.y = x.data_ptr(), out.data_ptr()
+        d.gamma = pr["gamma"].data_ptr() if pr.get("gamma") is not None else None
+        d.beta = pr["beta"].data_ptr() if pr.get("beta") is not None else None
+        d.HWC, d.N, d.C, d.G = x.numel() // N, N, Cc, pr["groups"]
+        d.relu, d.out_cstride, d.out_coff, d.eps, d.reserved = int(pr.get("relu", False)), out_cs, out_coff, float(pr.get("eps", 1e-5)), 0
+        ws_bytes += (int(lib.ml_groupnorm_workspace_bytes(N, pr["groups"])) + 255) // 256 * 256
+        nbytes += 8 * x.numel()
+        outs.append(out)
+    ws = workspace(ws_bytes, problems[0]["x"].device, "gn_multi")
+    with _Prof("groupnorm_chunk", 0, nbytes, f"multi x{n}"):
+        _lib.check(lib.ml_groupnorm_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_groupnorm_multi_f32")
+    return outs
+
+
 def resize_bilinear_ac(x, oh, ow, add=None, out=None, out_coff=0):
     lib = _lib.load()
     _require_dev(x, "x")

@@ -370,3 +370,29 @@ def test_global_mean_and_scale():
     np.testing.assert_allclose(host(ops.global_mean(dev(x)))[:, 0, 0], x.astype(np.float64).mean((1, 2)), atol=1e-5)
     s = rnd(3, 1, 1, 2048)
     np.testing.assert_allclose(host(ops.scale_channels_(dev(x), dev(s))), x * s, atol=1e-6)
+
+
+def test_groupnorm_multi_equals_single_launches():
+    """ml_groupnorm_multi_f32: the five pyramid levels of a tower depth (two-pass P3..P5, register-resident P6 / P7) and
+    a non-pixel-aligned RoI map in ONE launch pair -- bit-identical to the single-problem launches, and to the oracle."""
+    from masklab_hip import ops
+    shapes = [(2, 64, 64, 128, 16), (2, 32, 32, 128, 16), (2, 16, 16, 128, 16), (2, 8, 8, 128, 16), (2, 4, 4, 128, 16),
+              (9, 14, 14, 128, 16), (2, 16, 16, 128, 32)]
+    xs = [rnd(*s[:4]) + 0.5 for s in shapes]
+    gb = [(RNG.uniform(0.5, 1.5, s[3]).astype(np.float32), rnd(s[3])) for s in shapes]
+    single = [host(ops.groupnorm_chunk(dev(x), dev(g), dev(b), s[4])) for x, (g, b), s in zip(xs, gb, shapes)]
+    multi = ops.groupnorm_chunk_multi([dict(x=dev(x), gamma=dev(g), beta=dev(b), groups=s[4])
+                                       for x, (g, b), s in zip(xs, gb, shapes)])
+    for x, (g, b), s, one, m in zip(xs, gb, shapes, single, multi):
+        np.testing.assert_array_equal(host(m), one)
+        np.testing.assert_allclose(one, T.group_norm(x.astype(np.float64), g, b, s[4]), atol=2e-5)
+    # in place and with a fused ReLU into a concat slice
+    x0 = dev(xs[0].copy())
+    buf = torch.full((2, 32, 32, 160), 7.0, device="cuda")
+    outs = ops.groupnorm_chunk_multi([dict(x=x0, gamma=dev(gb[0][0]), beta=dev(gb[0][1]), groups=16, out=x0),
+                                      dict(x=dev(xs[1]), gamma=dev(gb[1][0]), beta=dev(gb[1][1]), groups=16, relu=True,
+                                           out=buf, out_coff=32)])
+    np.testing.assert_array_equal(host(outs[0]), single[0])
+    hb = host(buf)
+    assert np.all(hb[..., :32] == 7.0)
+    np.testing.assert_array_equal(hb[..., 32:], np.maximum(single[1], 0.0))
