@@ -161,10 +161,13 @@ conv_mfma_kernel(const MultiArgs args) {
     const int slice = id / P.blocks_per_split;
     id -= slice * P.blocks_per_split;
     const int NB = P.NB, M = P.M, ncpt = P.ncpt, ktot = P.ktot;
-    // XCD-aware tile assignment
+    // XCD-aware tile assignment: blocks whose ids are congruent mod 8 share an XCD (and its L2).  The NB column tiles of
+    // one 128-pixel A panel always do.  With a spatial kernel, vertically adjacent panels read each other's rows (taps
+    // kh = 0..2): each XCD then takes a CONTIGUOUS range of panels, so a halo row is fetched into one L2, not three
+    // (round-robin panels measured 2.0x the algorithmic HBM bytes on the tower convs, profiles/r02a_traffic.json).
     const int xcd = id & 7;
     const int jj = id >> 3;
-    const int mt = (jj / NB) * 8 + xcd;
+    const int mt = (p.KH > 1) ? xcd * ((P.MB + 7) >> 3) + jj / NB : (jj / NB) * 8 + xcd;
     const int nt = jj % NB;
     if (mt >= P.MB) return;
     const int m0 = mt * BM;

@@ -12,9 +12,18 @@ OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline"
+# (1a) kernels ALONE on the GPU (auxiliary streams off), like bench.py's instrumented roofline step: these average
+#      durations are the ones `roofline.avg_launch_us` must agree with
+export MASKLAB_SIDE_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
 python3 scripts/rocpd_summary.py $(find $OUT/trace -name "*.db" | head -1) $OUT/kernel_trace_summary.md > /dev/null
+unset MASKLAB_SIDE_STREAM
+# (1b) the headline command as it is timed: towers and the semantic head on auxiliary streams -- kernels overlap, so a
+#      kernel's duration here includes the time it shares the chip with another
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/trace_c -o trace -- $BENCH > $OUT/bench_trace_concurrent.log 2>&1
+python3 scripts/rocpd_summary.py $(find $OUT/trace_c -name "*.db" | head -1) $OUT/kernel_trace_concurrent_summary.md > /dev/null
 echo "trace done"
+export MASKLAB_SIDE_STREAM=0
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE; do
   name=${pass%%:*}; ctr=${pass#*:}
   rocprofv3 --kernel-trace --pmc ${ctr//,/ } --output-format rocpd -d $OUT/pmc_$name -o $name -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_pmc_$name.log 2>&1
@@ -23,4 +32,4 @@ for pass in fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_CYCLES,GRBM
 done
 python3 scripts/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $OUT/traffic.json
 grep '^{' $OUT/bench_trace.log | tail -1 > $OUT/bench_line.json
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma     # the SQLite results are large; the summaries are what travels back
+rm -rf $OUT/trace $OUT/trace_c $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma     # the SQLite results are large; the summaries are what travels back
