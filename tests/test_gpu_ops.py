@@ -377,7 +377,9 @@ def test_groupnorm_multi_equals_single_launches():
     a non-pixel-aligned RoI map in ONE launch pair -- bit-identical to the single-problem launches, and to the oracle."""
     from masklab_hip import ops
     shapes = [(2, 64, 64, 128, 16), (2, 32, 32, 128, 16), (2, 16, 16, 128, 16), (2, 8, 8, 128, 16), (2, 4, 4, 128, 16),
-              (9, 14, 14, 128, 16), (2, 16, 16, 128, 32)]
+              (9, 14, 14, 128, 16), (2, 16, 16, 128, 32),
+              (1, 128, 128, 128, 16),      # chunk 131 072 floats
+              (2, 80, 80, 128, 16)]        # chunk 51 200: slices that do not divide it
     xs = [rnd(*s[:4]) + 0.5 for s in shapes]
     gb = [(RNG.uniform(0.5, 1.5, s[3]).astype(np.float32), rnd(s[3])) for s in shapes]
     single = [host(ops.groupnorm_chunk(dev(x), dev(g), dev(b), s[4])) for x, (g, b), s in zip(xs, gb, shapes)]
@@ -386,6 +388,11 @@ def test_groupnorm_multi_equals_single_launches():
     for x, (g, b), s, one, m in zip(xs, gb, shapes, single, multi):
         np.testing.assert_array_equal(host(m), one)
         np.testing.assert_allclose(one, T.group_norm(x.astype(np.float64), g, b, s[4]), atol=2e-5)
+    # data whose mean dwarfs its spread (fp64 statistics)
+    big = (rnd(1, 128, 128, 32) + 1000.0).astype(np.float32)
+    g32, b32 = RNG.uniform(0.5, 1.5, 32).astype(np.float32), rnd(32)
+    got = host(ops.groupnorm_chunk(dev(big), dev(g32), dev(b32), 16))
+    np.testing.assert_allclose(got, T.group_norm(big.astype(np.float64), g32, b32, 16), atol=2e-3)
     # in place and with a fused ReLU into a concat slice
     x0 = dev(xs[0].copy())
     buf = torch.full((2, 32, 32, 160), 7.0, device="cuda")
