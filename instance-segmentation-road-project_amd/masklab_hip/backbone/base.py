@@ -142,14 +142,36 @@ class BackboneModel(Layer):
         x = self.preprocess(images)
         taps = self.body(x, wanted=self.taps)
         feats = [self.identities[k](taps[k]) for k in self.taps]
-        p6 = self.p6_conv(feats[-1])
+        # The extra levels are three small launches (16- and 4-tile convs, a 64-block GroupNorm: ~0.14 ms during which
+        # most of the chip idles).  A caller that has other work for the main stream (the FPN chain) passes
+        # `fork_stream` and joins `self.pending_stream` before it consumes P6 / P7.
+        fork = kwargs.get("fork_stream")
+        aux = fork("_extra_level_stream") if fork is not None else None
+        self.pending_stream = aux
+        import contextlib
+        import torch
+        with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            p6 = self.p6_conv(feats[-1])
+            g6 = self.p6_norm(p6)                              # new tensor: P6 itself stays intact
+            p7 = self.p7_conv(g6)
         if 'P6' in self.backbone_outputs:
             feats.append(p6)                                   # exported P6 is PRE-norm (:308-309)
-        g6 = self.p6_norm(p6)                                  # new tensor: P6 itself stays intact
-        p7 = self.p7_conv(g6)
         if 'P7' in self.backbone_outputs:
             feats.append(p7)
         return feats
+
+    def join_extra_levels(self, feats):
+        """Make the current stream wait for the P6 / P7 chain started by call(fork_stream=...)."""
+        import torch
+        aux = getattr(self, "pending_stream", None)
+        if aux is None:
+            return
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(aux)
+        for name, t in zip(self.output_names, feats):
+            if name in ("P6", "P7"):
+                t.record_stream(cur)
+        self.pending_stream = None
 
 
 def load_backbone(backbone_type="resnet50", backbone_outputs=('C3', 'C4', 'C5', 'P6', 'P7'), num_features=256):

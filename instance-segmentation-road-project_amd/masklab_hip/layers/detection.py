@@ -39,8 +39,15 @@ class FeaturePyramid(Layer):
         return [l for b in self.blocks for l in b]
 
     def call(self, inputs, **kwargs):
+        # The top-down chain (lateral -> resize + add -> next lateral ...) is serial, but the 3x3 output conv of a
+        # coarse level only reads its own merged map and is a 64- / 256-tile launch: with `fork_stream` those run on an
+        # auxiliary stream beside the chain; the finest level's conv (1024 tiles) closes the chain on the main stream.
+        fork = kwargs.get("fork_stream")
+        aux = fork("_fpn_stream") if fork is not None and len(inputs) > 1 else None
+        main = torch.cuda.current_stream() if aux is not None else None
         prev = None
         pyramid_outputs = []
+        last = len(inputs) - 1
         for idx, head in enumerate(inputs[::-1]):
             block = self.blocks[idx]
             lateral = block[0](head)
@@ -48,7 +55,17 @@ class FeaturePyramid(Layer):
                 # ResizeLike(prev -> lateral size) + Add, in place into `lateral` (reference :58-60)
                 ops.resize_bilinear_ac(prev, lateral.shape[1], lateral.shape[2], add=lateral, out=lateral)
             prev = lateral
-            pyramid_outputs.append(block[1](lateral))
+            if aux is not None and idx != last:
+                aux.wait_stream(main)
+                lateral.record_stream(aux)
+                with torch.cuda.stream(aux):
+                    pyramid_outputs.append(block[1](lateral))
+            else:
+                pyramid_outputs.append(block[1](lateral))
+        if aux is not None:
+            main.wait_stream(aux)
+            for t in pyramid_outputs[:-1]:
+                t.record_stream(main)
         return pyramid_outputs[::-1]
 
     def get_config(self):

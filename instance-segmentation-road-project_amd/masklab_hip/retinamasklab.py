@@ -207,7 +207,9 @@ class InferenceModel(K.Layer):
     def _stage1(self, images, want_kept=False):
         cfg = self.configuration
         bb = self.backbone_network
-        feats = bb(images)
+        fork_ok = getattr(self, "use_side_stream", False) and self.detection_networks is not None \
+            and hasattr(bb, "join_extra_levels")
+        feats = bb(images, fork_stream=self._fork_stream) if fork_ok else bb(images)
         by_name = dict(zip(bb.output_names, feats))
         st = {"image_hw": (int(images.shape[1]), int(images.shape[2]))}
 
@@ -243,7 +245,10 @@ class InferenceModel(K.Layer):
             pr_boxes = prior_subnet(images)
             fpn_inputs = [by_name[n] for n in bb.output_names if n in det_config.feature_pyramid_inputs]
             without_fpn = [by_name[n] for n in bb.output_names if n not in det_config.feature_pyramid_inputs]
-            feature_outputs = fpn_subnet(fpn_inputs) + without_fpn
+            feature_outputs = (fpn_subnet(fpn_inputs, fork_stream=self._fork_stream) if fork_ok
+                               else fpn_subnet(fpn_inputs)) + without_fpn
+            if fork_ok:
+                bb.join_extra_levels(feats)                    # P6 / P7 ran beside the FPN chain
             # The class and the box tower are independent chains of the same shape (5 levels x 4 convs, 1365 tiles per
             # launch = 2.67 rounds of the chip's 512 resident blocks): on two streams the last, partly filled round of
             # one launch is topped up by the other tower's blocks.  Same kernels, same inputs: bit-identical outputs.

@@ -5,9 +5,22 @@ import sqlite3
 import sys
 
 
+def sequence(con, pattern, out):
+    """Dispatches in start order with a marker on those matching `pattern` (context: 2 before, 1 after)."""
+    rows = con.execute("select name, start, end, stream_id from kernels order by start").fetchall()
+    hit = [i for i, r in enumerate(rows) if pattern in r[0]]
+    keep = sorted({j for i in hit for j in (i - 2, i - 1, i, i + 1) if 0 <= j < len(rows)})
+    with open(out, "w") as f:
+        for j in keep:
+            n, s, e, st = rows[j]
+            f.write(f"{j:6d} {'*' if pattern in n else ' '} stream {st} {(e - s) / 1e3:8.2f} us  {n[:100]}\n")
+
+
 def main():
     db = sys.argv[1]
     con = sqlite3.connect(db)
+    if len(sys.argv) > 4 and sys.argv[2] == "--sequence":
+        return sequence(con, sys.argv[3], sys.argv[4])
     rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
                        "from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1

@@ -33,6 +33,14 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_layer_names():
+    """Default layer names carry a per-session counter (`segmentation_sub_net_1` after another test built one):
+    the oracle functions look the weights up under the un-numbered default."""
+    from masklab_hip import keras_like as K
+    K.clear_session()
+
+
 def _loaded(layer, shape, seed=0):
     from masklab_hip import keras_like as K
     layer.build(shape)
