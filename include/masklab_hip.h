@@ -130,6 +130,29 @@ int ml_subsample2_f16(const void *in, void *out, int32_t B, int32_t H, int32_t W
 /* n halves -> n floats (the backbone taps handed to the fp32 heads), n % 8 == 0 */
 int ml_cast_f16_to_f32(const void *in, float *out, int64_t n, void *stream);
 
+/* ---------------------------------------------------------------- fused mask-head tail
+ * Conv2DTranspose(C_mid, (2,2), (2,2)) + bias + act_mid followed by Conv2D(ncls, (1,1)) + bias + act_out in one
+ * kernel (reference engine/layers/instance.py:196-201 constructs the pair, :226-233 calls it; replaces the
+ * tf.nn.conv2d_transpose -> tf.nn.conv2d pair).  Up to 4 problems (RoI levels, each with its own weights) per launch.
+ *   x        [M, K] fp32, M = rois * hw input pixels (whole h x w maps, RoIs grouped per image: rois = B * rois_per_image)
+ *   wd       [4][C_mid][K]: position q = dy*2+dx major, k contiguous (the ml_conv2d_desc packing of the transposed conv)
+ *   bd       [C_mid] or NULL;   bo [ncls] or NULL
+ *   wo_table [C_mid/32][16][2][cp]: entry (t, e, half, c) = W_out[32 t + (e & 3) + 8 (e >> 2) + 4 half][c] (0 for
+ *            c >= ncls) -- the 1x1 kernel's rows in the order the matrix cores' accumulator registers hold channels;
+ *            cp = power of two >= ncls
+ *   out      element (img, j, 2y+dy, 2x+dx, c) of RoI j of image img at
+ *            out[img * out_image_stride + out_base + j * (4 hw ncls) + ((2y+dy) * 2w + 2x+dx) * ncls + c]
+ * K % 32 == 0, C_mid in {128, 256}, ncls <= 32, M < 2^24 per problem. */
+typedef struct ml_deconv_out_problem {
+    const float *x, *wd, *bd, *wo_table, *bo;
+    float *out;
+    int64_t M;
+    int32_t hw, w, rois_per_image, reserved0;
+    int64_t out_image_stride, out_base;
+} ml_deconv_out_problem;
+int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid, int32_t ncls,
+                            int32_t cp, int32_t act_mid, int32_t act_out, void *stream);
+
 /* ---------------------------------------------------------------- depthwise / pooling
  * 3x3 DepthwiseConv2D (depth_multiplier 1), stride 1/2, dilation, explicit pads, +bias
  * (folded BN) +activation.  tf.keras.applications MobileNet body; semantic.py:63; misc.py:85.

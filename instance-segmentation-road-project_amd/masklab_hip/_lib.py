@@ -43,7 +43,16 @@ class GnDesc(C.Structure):
                 ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32)]
 
 
+class DeconvOutProblem(C.Structure):
+    """Mirror of `ml_deconv_out_problem` (include/masklab_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p), ("wo_table", C.c_void_p),
+                ("bo", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("hw", C.c_int32), ("w", C.c_int32),
+                ("rois_per_image", C.c_int32), ("reserved0", C.c_int32), ("out_image_stride", C.c_int64),
+                ("out_base", C.c_int64)]
+
+
 GN_MAX_PROBLEMS = 8
+DECONV_OUT_MAX_PROBLEMS = 4
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/masklab_hip.h declares
@@ -56,6 +65,7 @@ SIGNATURES = {
     "ml_conv2d_uses_pipe": (C.c_int, [C.POINTER(ConvDesc)]),
     "ml_conv2d_workspace_bytes": (_i64, []),
     "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
+    "ml_deconv2x2_out1x1_f32": (C.c_int, [C.POINTER(DeconvOutProblem), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ml_gconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_gconv3x3_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_maxpool3x3s2_f16": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),

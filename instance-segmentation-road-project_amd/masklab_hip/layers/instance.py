@@ -118,6 +118,41 @@ class MaskSubNet(Layer, _TowerMixin):
     def children(self):
         return [l for b in self.blocks for l in b]
 
+    def load_weights(self, weights, device):
+        super().load_weights(weights, device)
+        # the 1x1 output kernels once more, in the lane order of the fused tail kernel (csrc/deconv_out.hip)
+        from .. import packing
+        self._tail_tables = []
+        for block in self.blocks:
+            deconv, out = block[-2], block[-1]
+            p = deconv.dev.p
+            ok = (p.span == p.span_pad and p.n_pad == p.cout and p.cout // 4 in (128, 256) and self.num_classes <= 32
+                  and out.kernel_size == (1, 1) and out.strides == (1, 1))
+            if not ok:
+                self._tail_tables = None
+                break
+            k, b = out.folded(weights)
+            table, bo, _ = packing.pack_out1x1_table(k, b)
+            self._tail_tables.append((torch.from_numpy(table).to(device), torch.from_numpy(bo).to(device)))
+
+    def _fused_tail(self, blocks, xs, shapes, roi_masks, per_roi):
+        """Conv2DTranspose + ReLU -> Conv2D 1x1 + sigmoid of every level in one launch, written straight into
+        `roi_masks` (csrc/deconv_out.hip); False when the configuration is outside that kernel's shapes."""
+        from .. import _lib
+        if getattr(self, "_tail_tables", None) is None or ops.CONV_MATH == "f16":
+            return False
+        if any(x.dtype != torch.float32 or x.shape[0] * x.shape[1] * x.shape[2] >= 1 << 24 for x in xs):
+            return False
+        problems, off = [], 0
+        for i, ((_, n), b, x) in enumerate(zip(shapes, blocks, xs)):
+            table, bo = self._tail_tables[i]
+            problems.append(dict(x=x.contiguous(), dc=b[-2].dev, wo_table=table, bo=bo, out=roi_masks,
+                                 out_base=off * per_roi, rois_per_image=n))
+            off += n
+        ops.deconv2x2_out1x1_multi(problems, self.num_classes, _lib.ACT_BY_NAME[blocks[0][-2].activation],
+                                   _lib.ACT_BY_NAME[blocks[0][-1].activation])
+        return True
+
     def call(self, inputs, **kwargs):
         if not isinstance(inputs, list):
             inputs = [inputs]
@@ -127,6 +162,13 @@ class MaskSubNet(Layer, _TowerMixin):
         # fold rois into the batch (:211-213); all levels advance together (multi-problem launches)
         xs = [h.reshape((h.shape[0] * h.shape[1],) + tuple(h.shape[2:])) for h in inputs]
         xs = self._run_towers_multi([b[:-2] for b in blocks], xs)
+        if all(n > 0 for _, n in shapes):
+            B = shapes[0][0]
+            oh, ow, ncls = 2 * int(xs[0].shape[1]), 2 * int(xs[0].shape[2]), self.num_classes
+            total = sum(n for _, n in shapes)
+            roi_masks = torch.empty((B, total, oh, ow, ncls), dtype=torch.float32, device=xs[0].device)
+            if self._fused_tail(blocks, xs, shapes, roi_masks, oh * ow * ncls):
+                return roi_masks
         xs = ops.conv2d_multi([dict(x=x, dc=b[-2].dev, act=_lib.ACT_BY_NAME[b[-2].activation])
                                for b, x in zip(blocks, xs)])                    # Conv2DTranspose + ReLU
         # unfold + Concatenate(axis=1) (:222-225) fused into the output convs: level l's [B*n_l, h, w, classes] maps

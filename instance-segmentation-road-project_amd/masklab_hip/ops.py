@@ -235,6 +235,54 @@ def conv2d_multi(problems):
     return rets
 
 
+def deconv2x2_out1x1_multi(problems, ncls, act_mid, act_out):
+    """ml_deconv2x2_out1x1_f32: Conv2DTranspose(2x2, s2) + act_mid -> Conv2D 1x1 + act_out, up to 4 RoI levels per launch.
+    problems: dicts x [R,h,w,K] fp32 (R = images * rois_per_image), dc (DeviceConv of the transposed conv), wo_table,
+    bo (device tensors from packing.pack_out1x1_table), out (the [B,total,2h,2w,ncls] tensor), out_base (elements),
+    rois_per_image."""
+    lib = _lib.load()
+    n = len(problems)
+    if n == 0:
+        return
+    if n > _lib.DECONV_OUT_MAX_PROBLEMS:
+        deconv2x2_out1x1_multi(problems[:_lib.DECONV_OUT_MAX_PROBLEMS], ncls, act_mid, act_out)
+        deconv2x2_out1x1_multi(problems[_lib.DECONV_OUT_MAX_PROBLEMS:], ncls, act_mid, act_out)
+        return
+    arr = (_lib.DeconvOutProblem * n)()
+    flops = nbytes = 0.0
+    K = cmid = cp = None
+    for i, pr in enumerate(problems):
+        x, dc, out = pr["x"], pr["dc"], pr["out"]
+        _require_dev(x, "x")
+        _require_dev(out, "out")
+        if x.dtype != torch.float32 or not x.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("deconv2x2_out1x1: x must be a contiguous fp32 [R,h,w,K] tensor, out fp32")
+        R, h, w, Kx = x.shape
+        p = dc.p
+        if not p.shuffle2x2 or p.span != Kx or p.span_pad != Kx or p.cout % 4 or p.n_pad != p.cout:
+            raise ValueError("deconv2x2_out1x1: `dc` must be a packed Conv2DTranspose whose input width is a multiple of 32")
+        if K is None:
+            K, cmid, cp = Kx, p.cout // 4, int(pr["wo_table"].shape[-1])
+        elif (K, cmid, cp) != (Kx, p.cout // 4, int(pr["wo_table"].shape[-1])):
+            raise ValueError("deconv2x2_out1x1: the problems of one launch must share K, C_mid and the table width")
+        if tuple(pr["wo_table"].shape) != (cmid // 32, 16, 2, cp):
+            raise ValueError("deconv2x2_out1x1: wo_table has the wrong shape")
+        n_l = int(pr["rois_per_image"])
+        d = arr[i]
+        d.x, d.wd, d.bd = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
+        d.wo_table, d.bo, d.out = pr["wo_table"].data_ptr(), pr["bo"].data_ptr(), out.data_ptr()
+        d.M, d.hw, d.w, d.rois_per_image, d.reserved0 = R * h * w, h * w, w, n_l, 0
+        d.out_image_stride, d.out_base = out.stride(0), int(pr["out_base"])
+        last = (R // n_l - 1) * out.stride(0) + int(pr["out_base"]) + n_l * 4 * h * w * ncls
+        if R % n_l or last > out.numel():
+            raise ValueError("deconv2x2_out1x1: the RoI block does not fit the output tensor")
+        flops += 2.0 * R * h * w * (4 * cmid * Kx + 4 * cmid * ncls)
+        nbytes += 4.0 * (x.numel() + 4 * R * h * w * ncls + 4 * cmid * Kx)
+    with _Prof("deconv2x2_out1x1", flops, nbytes, f"multi x{n}"):
+        _lib.check(lib.ml_deconv2x2_out1x1_f32(arr, n, K, cmid, ncls, cp, act_mid, act_out, _stream()),
+                   "ml_deconv2x2_out1x1_f32")
+
+
 def gconv3x3(x, wgt, bias, c, stride=1, padding=((1, 1), (1, 1)), act=_lib.ACT_NONE):
     """ml_gconv3x3_f32: ResNeXt grouped 3x3, wgt [C,9,c] (packing.pack_grouped_mfma4)."""
     lib = _lib.load()

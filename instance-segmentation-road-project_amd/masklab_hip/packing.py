@@ -188,6 +188,27 @@ def pack_transpose2x2(kernel, bias=None, tile=0):
                       tile=tile, cin_buffer=cin, k_real=cin)
 
 
+def pack_out1x1_table(kernel, bias=None):
+    """1x1 conv kernel [1,1,C_mid,ncls] -> the lane table of ml_deconv2x2_out1x1_f32 (include/masklab_hip.h):
+    [C_mid/32][16][2][cp], entry (t, e, half, c) = kernel[32 t + (e & 3) + 8 (e >> 2) + 4 half, c]; cp = the power of two
+    >= ncls.  Returns (table, bias padded to cp, cp)."""
+    assert kernel.shape[:2] == (1, 1)
+    cmid, ncls = int(kernel.shape[2]), int(kernel.shape[3])
+    if cmid % 32 or ncls > 32:
+        raise ValueError("fused mask-head tail needs C_mid % 32 == 0 and at most 32 classes")
+    cp = 1
+    while cp < ncls:
+        cp *= 2
+    t, e, h = np.meshgrid(np.arange(cmid // 32), np.arange(16), np.arange(2), indexing="ij")
+    ch = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h
+    table = np.zeros((cmid // 32, 16, 2, cp), np.float32)
+    table[..., :ncls] = kernel[0, 0][ch]
+    b = np.zeros((cp,), np.float32)
+    if bias is not None:
+        b[:ncls] = bias
+    return np.ascontiguousarray(table), b, cp
+
+
 def pack_depthwise(dw_kernel):
     """DepthwiseConv2D kernel [3,3,C,1] -> [9][C]."""
     kh, kw, C, mult = dw_kernel.shape

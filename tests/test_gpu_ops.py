@@ -208,6 +208,49 @@ def test_conv2d_transpose2x2():
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("cmid,K,ncls,levels", [(128, 128, 3, [(2, 3), (2, 1), (2, 5)]),      # the benchmark's mask head
+                                               (256, 256, 3, [(1, 2), (1, 3)]),             # Keras default width
+                                               (128, 96, 20, [(3, 4)]),                     # 20 classes: 32-wide table
+                                               (128, 128, 1, [(2, 7), (2, 2), (2, 1), (2, 4)])])
+def test_deconv2x2_out1x1_fused_tail(cmid, K, ncls, levels):
+    """csrc/deconv_out.hip (MaskSubNet tail, instance.py:196-201,226-233): Conv2DTranspose 2x2 s2 + ReLU -> Conv2D 1x1 +
+    sigmoid per RoI level with its own weights, all levels in one launch, written into the image-major
+    [B, total, 2h, 2w, ncls] tensor at each level's RoI offset; partly filled 128-pixel tiles at every level end."""
+    from masklab_hip import _lib, ops, packing
+    h, w_ = 14, 14
+    B = levels[0][0]
+    total = sum(n for _, n in levels)
+    out = torch.full((B, total, 2 * h, 2 * w_, ncls), -7.0, device="cuda")
+    per_roi = 4 * h * w_ * ncls
+    want = np.zeros((B, total, 2 * h, 2 * w_, ncls))
+    problems, off = [], 0
+    for _, n in levels:
+        x = rnd(B * n, h, w_, K)
+        wd, bd = rnd(2, 2, cmid, K, scale=0.05), rnd(cmid)
+        wo, bo = rnd(1, 1, cmid, ncls, scale=0.1), rnd(ncls)
+        t = T.relu(T.conv2d_transpose_2x2_s2(x.astype(np.float64), wd, bd))
+        y = T.sigmoid(T.conv2d(t, wo, bo))
+        want[:, off:off + n] = y.reshape(B, n, 2 * h, 2 * w_, ncls)
+        table, bo_p, cp = packing.pack_out1x1_table(wo, bo)
+        problems.append(dict(x=dev(x), dc=ops.DeviceConv(packing.pack_transpose2x2(wd, bd), "cuda"),
+                             wo_table=dev(table), bo=dev(bo_p), out=out, out_base=off * per_roi, rois_per_image=n))
+        off += n
+    ops.deconv2x2_out1x1_multi(problems, ncls, _lib.ACT_RELU, _lib.ACT_SIGMOID)
+    np.testing.assert_allclose(host(out), want, atol=2e-5)
+
+
+def test_deconv2x2_out1x1_rejects_bad_shapes():
+    from masklab_hip import _lib, ops, packing
+    x = dev(rnd(2, 14, 14, 64))
+    wd, wo = rnd(2, 2, 64, 64, scale=0.05), rnd(1, 1, 64, 3)
+    table, bo, _ = packing.pack_out1x1_table(wo, None)
+    out = torch.zeros((2, 1, 28, 28, 3), device="cuda")
+    with pytest.raises(RuntimeError, match="128 or 256"):
+        ops.deconv2x2_out1x1_multi([dict(x=x, dc=ops.DeviceConv(packing.pack_transpose2x2(wd, None), "cuda"),
+                                         wo_table=dev(table), bo=dev(bo), out=out, out_base=0, rois_per_image=1)],
+                                   3, _lib.ACT_RELU, _lib.ACT_SIGMOID)
+
+
 @pytest.mark.parametrize("k,cin,cout,hw,stride", [(3, 2048, 128, (6, 6), 2), (1, 2048, 128, (16, 16), 1),
                                                   (1, 2048, 128, (1, 1), 1), (3, 128, 128, (8, 8), 1),
                                                   (1, 640, 128, (32, 32), 1), (3, 256, 75, (4, 4), 1)])
