@@ -504,12 +504,22 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     // enough work units to fill every resident block (2 per CU), and at most PIPE_MAX_NBG N tiles per block: split a
     // panel's N tiles into 2^gshift groups
     const int resident = 512;
-    A.gshift = 0;
-    while (((long long)A.panels << A.gshift < resident || (A.NB >> A.gshift) > PIPE_MAX_NBG) && (A.NB >> A.gshift) % 2 == 0 &&
-           (A.NB >> A.gshift) > 1)
-        ++A.gshift;
+    // Split a panel's N tiles into 2^gshift groups (a unit = one group of one panel).  Blocks are persistent and take
+    // units round-robin, so the launch lasts ceil(units / resident) units: pick the split whose last round is fullest
+    // (800 panels: 1 group -> 2 rounds for 1.56 rounds of work, 4 groups -> 7 for 6.25), the coarser one on a near tie
+    // (a coarser unit re-reads the panel's activations from L2 less often).
+    int best = -1;
+    double best_eff = -1.0;
+    for (int g = 0; (A.NB >> g) >= 1 && (A.NB % (1 << g)) == 0; ++g) {
+        if ((A.NB >> g) > PIPE_MAX_NBG) continue;
+        const long long units = (long long)A.panels << g;
+        const long long rounds = (units + resident - 1) / resident;
+        const double eff = (double)units / (double)(rounds * resident);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+    }
+    if (best < 0) return ML_OK;                           // (an odd tile count above the limit: the generic kernel)
+    A.gshift = best;
     A.NBG = A.NB >> A.gshift;
-    if (A.NBG > PIPE_MAX_NBG) return ML_OK;              // (an odd tile count above the limit: the generic kernel)
     A.units = A.panels << A.gshift;
     A.grid = A.units < resident ? A.units : resident;
     A.lo = d.act == ML_ACT_NONE ? -3.402823466e38f : 0.f;

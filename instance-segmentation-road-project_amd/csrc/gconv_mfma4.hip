@@ -163,6 +163,116 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
     }
 }
 
+// ---- fp16 storage (BASELINE config 5): the same decomposition on v_mfma_f32_4x4x4_16B_f16 -- one instruction contracts
+// the 4 input channels that took four 4x4x1 fp32 instructions, operands are the tensor's own halves (the halo tile
+// stays fp16 in LDS, staged with plain 16-byte copies) and the weights are rounded to fp16 once per block: the "fp16
+// MFMA path" proper.  fp32 accumulation, bias and activation; ONE rounding at the store.
+//   A: lane 4b+i holds W[out 4b+i][in i0 .. i0+3]; B: lane 4b+j holds X[pixel j][in i0 .. i0+3]; D as above.
+// Pixel stride in LDS: 192 B (stride 1) / 160 B (stride 2) -- the four pixels of a quad, 64 B per half-wave each,
+// land on disjoint bank quarters for ds_read_b64.
+template <int STRIDE> struct PixH { static constexpr int value = STRIDE == 1 ? 96 : 80; };   // halves per halo pixel
+
+template <int STRIDE, int TH, int TW, int CPG>
+__global__ void __launch_bounds__(256)
+gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+                    _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
+                    int tiles_x) {
+    constexpr int c = CPG;
+    constexpr int PSH = PixH<STRIDE>::value;
+    constexpr int THIN = (TH - 1) * STRIDE + 3;
+    constexpr int TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int NPIX = THIN * TWIN;
+    constexpr int TPP = CS / 8;                 // threads per halo pixel (8 halves each)
+    constexpr int PPP = 256 / TPP;
+    constexpr int NLD = (NPIX + PPP - 1) / PPP;
+    constexpr int QUADS = TH * TW / 4;
+    constexpr int QPW = QUADS / 4;
+    constexpr int WV = 9 * c / 4;
+    static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
+    extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PSH]
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int blk = lane >> 2, sub = lane & 3;
+
+    f16x8g stage[NLD];
+    {
+        const int cN = (tid % TPP) * 8;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid / TPP + PPP * i;
+            const int py = p / TWIN, px = p - py * TWIN;
+            const int iy = iy0 + py, ix = ix0 + px;
+            f16x8g v = {};
+            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+            stage[i] = v;
+        }
+    }
+    f16x4g wv[WV];
+    {
+        const float *wrow = wgt + (long long)(cs0 + blk * 4 + sub) * 9 * c;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+            wv[i] = f16x4g{(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
+        }
+    }
+    {
+        const int cN = (tid % TPP) * 8;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid / TPP + PPP * i;
+            if (p < NPIX) *reinterpret_cast<f16x8g *>(tileh + p * PSH + cN) = stage[i];
+        }
+    }
+    __syncthreads();
+
+    const int gch = ((cs0 + blk * 4) / c) * c - cs0;
+    f32x4 acc[QPW];
+    int qbase[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int quad = wave * QPW + q;
+        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
+        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PSH + gch;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * TWIN + (t % 3)) * PSH;
+#pragma unroll
+        for (int i0 = 0; i0 < c; i0 += 4) {
+            const f16x4g w4 = wv[(t * c + i0) / 4];
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) {
+                const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + qbase[q] + toff + i0);
+                acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(w4, xv, acc[q], 0, 0, 0);
+            }
+        }
+    }
+
+    const int oc = cs0 + blk * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int quad = wave * QPW + q;
+        const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
+        if (oy >= Ho || ox >= Wo) continue;
+        f32x4 v = acc[q] + bv;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+        store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+    }
+}
+
 // ---- c = 16: one group is a full 16 x 16 block, so v_mfma_f32_16x16x4_f32 wastes nothing either and needs a
 // quarter of the operand traffic per flop: D[out 16][pixel 16] += W[out][in 4] * X[in 4][pixel].
 //   A: lane (i = l & 15, q = l >> 4) holds W[out i][in 4q + s] for k-step s   (9 float4 per lane, in registers)
@@ -263,12 +373,118 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
     }
 }
 
+// fp16 storage: c = 16 on v_mfma_f32_16x16x16_f16 -- ONE instruction per tap and 16-pixel set contracts the group's 16
+// input channels (four 16x16x4 fp32 instructions before); lane (j, q) supplies the same 4 channels 4q .. 4q+3, as halves.
+constexpr int PS16H = 72;  // LDS halves per pixel (144 B)
+
+template <int STRIDE, int TH, int TW>
+__global__ void __launch_bounds__(256)
+gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
+                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+    constexpr int THIN = (TH - 1) * STRIDE + 3;
+    constexpr int TWIN = (TW - 1) * STRIDE + 3;
+    constexpr int NPIX = THIN * TWIN;
+    constexpr int TPP = CS / 8;
+    constexpr int PPP = 256 / TPP;
+    constexpr int NLD = (NPIX + PPP - 1) / PPP;
+    constexpr int SETS = TH * TW / 16;
+    static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
+    extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PS16H]
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+
+    f16x8g stage[NLD];
+    {
+        const int cN = (tid % TPP) * 8;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid / TPP + PPP * i;
+            const int py = p / TWIN, px = p - py * TWIN;
+            const int iy = iy0 + py, ix = ix0 + px;
+            f16x8g v = {};
+            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+            stage[i] = v;
+        }
+    }
+    f16x4g wv[9];
+    {
+        const float *wrow = wgt + (long long)(cs0 + wave * 16 + j) * 9 * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + t * 16);
+            wv[t] = f16x4g{(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
+        }
+    }
+    {
+        const int cN = (tid % TPP) * 8;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid / TPP + PPP * i;
+            if (p < NPIX) *reinterpret_cast<f16x8g *>(tileh + p * PS16H + cN) = stage[i];
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[SETS];
+    int pbase[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int py = 2 * s + (j >> 3), px = j & 7;
+        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16H + wave * 16 + 4 * q;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * TWIN + (t % 3)) * PS16H;
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) {
+            const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + pbase[s] + toff);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x16f16(wv[t], xv, acc[s], 0, 0, 0);
+        }
+    }
+
+    const int oc = cs0 + wave * 16 + 4 * q;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
+        if (oy >= Ho || ox >= Wo) continue;
+        const f32x4 v = acc[s] + bv;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+        store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+    }
+}
+
+// kernel of a tensor type: fp32 tensors -> the fp32 MFMA forms, fp16 tensors -> the fp16 MFMA forms
+template <int STRIDE, int TH, int TW, class TIO>
+auto pick16() {
+    if constexpr (sizeof(TIO) == 2) return gconv16h_kernel<STRIDE, TH, TW>;
+    else return gconv16_kernel<STRIDE, TH, TW, TIO>;
+}
+template <int STRIDE, int TH, int TW, int CPG, class TIO>
+auto pick4() {
+    if constexpr (sizeof(TIO) == 2) return gconv_mfma4h_kernel<STRIDE, TH, TW, CPG>;
+    else return gconv_mfma4_kernel<STRIDE, TH, TW, CPG, TIO>;
+}
+
 template <int STRIDE, int TH, int TW, class TIO>
 int launch16(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, int H, int W, int C, int Ho, int Wo,
              int pad_t, int pad_l, int act, hipStream_t s) {
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
-    constexpr int LDS_BYTES = THIN * TWIN * PS16 * 4;
-    auto kern = gconv16_kernel<STRIDE, TH, TW, TIO>;
+    constexpr bool HALF = sizeof(TIO) == 2;
+    constexpr int LDS_BYTES = HALF ? THIN * TWIN * PS16H * 2 : THIN * TWIN * PS16 * 4;
+    auto kern = pick16<STRIDE, TH, TW, TIO>();
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
@@ -282,8 +498,9 @@ template <int STRIDE, int TH, int TW, int CPG, class TIO>
 int launch(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, int H, int W, int C, int Ho,
            int Wo, int pad_t, int pad_l, int act, hipStream_t s) {
     constexpr int THIN = (TH - 1) * STRIDE + 3, TWIN = (TW - 1) * STRIDE + 3;
-    constexpr int LDS_BYTES = THIN * TWIN * PS * 4;
-    auto kern = gconv_mfma4_kernel<STRIDE, TH, TW, CPG, TIO>;
+    constexpr bool HALF = sizeof(TIO) == 2;
+    constexpr int LDS_BYTES = HALF ? THIN * TWIN * PixH<STRIDE>::value * 2 : THIN * TWIN * PS * 4;
+    auto kern = pick4<STRIDE, TH, TW, CPG, TIO>();
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;

@@ -84,13 +84,17 @@ def test_conv1x1_half_storage(cin, cout, hw, B, res, act, stride):
 
 
 @pytest.mark.parametrize("c,C,stride,hw", [(4, 128, 1, (24, 20)), (8, 256, 2, (20, 24)), (16, 512, 1, (16, 16)),
-                                           (4, 128, 2, (17, 19))])
+                                           (4, 128, 2, (17, 19)), (8, 256, 1, (9, 30)), (16, 512, 2, (19, 21)),
+                                           (16, 1024, 1, (5, 7))])
 def test_grouped3x3_half_storage(c, C, stride, hw):
+    """fp16 tensors run the grouped 3x3 on the fp16 matrix instructions (v_mfma_f32_4x4x4_16B_f16 for c = 4 / 8,
+    v_mfma_f32_16x16x16_f16 for c = 16): activations are the tensor's own halves, the kernel is rounded to half once per
+    block, products exact, fp32 accumulation -- so the oracle gets BOTH operands half-rounded"""
     from masklab_hip import _lib, ops, packing
     groups = C // c
     x = to_half(rnd(2, hw[0], hw[1], C))
     k, b = rnd(3, 3, C, c, scale=1.0 / np.sqrt(9 * c)), rnd(C)
-    ref = O.grouped_conv_fast(x.astype(np.float64), k.astype(np.float64), groups, c, stride) + b.astype(np.float64)
+    ref = O.grouped_conv_fast(x.astype(np.float64), h64(k), groups, c, stride) + b.astype(np.float64)
     ref = T.relu(ref).astype(np.float16)
     got = ops.gconv3x3(dev(x), dev(packing.pack_grouped_mfma4(k, groups)), dev(b), c, stride=stride,
                        padding=((1, 1), (1, 1)), act=_lib.ACT_RELU)

@@ -361,3 +361,32 @@ def test_keras_h5_converter_maps_reference_auto_names_by_creation_order(flags, u
     fewer = {k: v for k, v in got.items() if k not in dropped}
     with pytest.raises(ValueError, match="different head configuration"):
         conv.rename_keras_auto_names(fewer, specs)
+
+
+def test_out1x1_lane_table_reproduces_the_1x1_conv():
+    """packing.pack_out1x1_table (operand of ml_deconv2x2_out1x1_f32): emulate what the kernel does with it -- the
+    transposed product leaves, in lane l / register e of channel tile t, channel 32t + (e&3) + 8(e>>2) + 4(l>>5) of
+    pixel l&31; one MFMA per register then contracts the two lane halves against table[t][e][half][class] -- and
+    compare with the plain 1x1 conv."""
+    from masklab_hip import packing
+    rng = np.random.default_rng(5)
+    for cmid, ncls in [(128, 3), (256, 1), (128, 20), (128, 32)]:
+        k = rng.normal(size=(1, 1, cmid, ncls)).astype(np.float32)
+        b = rng.normal(size=(ncls,)).astype(np.float32)
+        table, bo, cp = packing.pack_out1x1_table(k, b)
+        assert cp >= ncls and cp & (cp - 1) == 0 and cp < 2 * max(ncls, 1) + 1
+        assert table.shape == (cmid // 32, 16, 2, cp) and bo.shape == (cp,)
+        assert not table[..., ncls:].any() and not bo[ncls:].any()
+        t_act = rng.normal(size=(32, cmid))                      # [pixel, channel]: the activated transposed-conv tile
+        y = np.tile(bo.astype(np.float64), (32, 1))
+        for t in range(cmid // 32):
+            for e in range(16):
+                for half in range(2):                            # the MFMA's k index = lane half
+                    ch = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * half
+                    y += np.outer(t_act[:, ch], table[t, e, half].astype(np.float64))
+        want = t_act @ k[0, 0].astype(np.float64) + b
+        np.testing.assert_allclose(y[:, :ncls], want, atol=1e-12)
+    with pytest.raises(ValueError):
+        packing.pack_out1x1_table(np.zeros((1, 1, 128, 33), np.float32))
+    with pytest.raises(ValueError):
+        packing.pack_out1x1_table(np.zeros((1, 1, 100, 3), np.float32))
