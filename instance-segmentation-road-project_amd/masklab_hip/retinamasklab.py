@@ -6,8 +6,6 @@ Same function names, argument meaning and return structure; the returned model r
 the MI355X kernels.  Training-only pieces (construct_trainer_network, losses, dataset) are out of
 scope of the accelerated path.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -233,14 +231,13 @@ class InferenceModel(K.Layer):
                 return None
             main = torch.cuda.current_stream()
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MASKLAB_SIDE_PRIO", "0")))
+                self._side_stream = torch.cuda.Stream(device=self.device)
             self._side_stream.wait_stream(main)
             with torch.cuda.stream(self._side_stream):
                 st["seg_pred"] = semantic_head()
             return self._side_stream
 
-        early = os.environ.get("MASKLAB_SEMANTIC_EARLY") == "1"
-        if self.detection_networks is None or early:
+        if self.detection_networks is None:
             side = launch_semantic_on_side()
         if self.detection_networks is not None:
             det_config = cfg.detection
@@ -265,8 +262,7 @@ class InferenceModel(K.Layer):
             else:
                 st["cls_pred"] = cls_subnet(feature_outputs)
                 st["loc_pred"] = loc_subnet(feature_outputs)
-            if not early:
-                side = launch_semantic_on_side()
+            side = launch_semantic_on_side()
             if self.instance_networks is not None:
                 restore_subnet, distribute_subnet, pyramid_roi_align, _ = self.instance_networks
                 restored_boxes = restore_subnet([st["loc_pred"], pr_boxes])
@@ -300,7 +296,7 @@ class InferenceModel(K.Layer):
             return None
         s = getattr(self, attr, None)
         if s is None:
-            s = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("MASKLAB_HI") == "1" else 0)
+            s = torch.cuda.Stream(device=self.device)
             setattr(self, attr, s)
         s.wait_stream(torch.cuda.current_stream())
         return s
@@ -366,17 +362,6 @@ class InferenceModel(K.Layer):
         images = images.to(self.device).contiguous()
         want_kept = kwargs.get("want_kept", False)
         from . import ops
-        if os.environ.get("MASKLAB_HI") == "1" and ops.PROFILE is None:
-            if getattr(self, "_hi_stream", None) is None:
-                self._hi_stream = torch.cuda.Stream(device=self.device, priority=-1)
-            cur = torch.cuda.current_stream()
-            self._hi_stream.wait_stream(cur)
-            with torch.cuda.stream(self._hi_stream):
-                outs = self._stage2(self._stage1(images, want_kept=want_kept))
-            cur.wait_stream(self._hi_stream)
-            for o in outs:
-                o.record_stream(cur)
-            return outs
         if getattr(self, "_use_graphs", False) and not want_kept and ops.PROFILE is None:
             st = self._stage1_graphed(images)
         else:
