@@ -76,6 +76,10 @@ def test_conv2d_dense(k, cin, cout, stride, padding, dil, act, hw):
     (256, 512, (16, 16), 2, True, "relu6", False),      # few panels: N tiles split over work units
     (512, 1024, (8, 8), 1, True, "relu", False),        # one panel, 8 N tiles in 8 units
     (96, 128, (20, 20), 1, False, "relu", False),       # K = 96: three chunks
+    (128, 384, (40, 40), 2, True, "relu", False),       # 3 N tiles: an odd count cannot be split, one unit per panel
+    (64, 768, (64, 64), 1, False, "relu", False),       # 6 N tiles: split in two groups of 3
+    (128, 640, (24, 24), 3, True, None, False),         # 5 N tiles, 14 panels (M tail of 64 rows)
+    (64, 256, (80, 80), 16, True, "relu", False),       # 800 panels: the split that fills the last round (4 rounds of 2 groups)
 ])
 def test_conv1x1_pipelined_kernel(cin, cout, hw, B, res, act, in_slice):
     """csrc/conv1x1_pipe.hip (tile = 4): the persistent, tile-pipelined 1x1 conv of the ResNeXt bottleneck blocks
@@ -208,16 +212,20 @@ def test_conv2d_transpose2x2():
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
-@pytest.mark.parametrize("cmid,K,ncls,levels", [(128, 128, 3, [(2, 3), (2, 1), (2, 5)]),      # the benchmark's mask head
-                                               (256, 256, 3, [(1, 2), (1, 3)]),             # Keras default width
-                                               (128, 96, 20, [(3, 4)]),                     # 20 classes: 32-wide table
-                                               (128, 128, 1, [(2, 7), (2, 2), (2, 1), (2, 4)])])
-def test_deconv2x2_out1x1_fused_tail(cmid, K, ncls, levels):
+@pytest.mark.parametrize("cmid,K,ncls,levels,hw", [
+    (128, 128, 3, [(2, 3), (2, 1), (2, 5)], (14, 14)),           # the benchmark's mask head
+    (256, 256, 3, [(1, 2), (1, 3)], (14, 14)),                   # Keras default width
+    (128, 96, 20, [(3, 4)], (14, 14)),                           # 20 classes: 32-wide table
+    (128, 128, 1, [(2, 7), (2, 2), (2, 1), (2, 4)], (14, 14)),
+    (128, 64, 5, [(2, 9), (2, 30)], (7, 7)),                     # crop_size 7: RoI maps smaller than a tile row group
+    (128, 128, 2, [(1, 3), (1, 2)], (6, 10)),                    # non-square crop
+    (128, 128, 3, [(8, 100)], (14, 14))])                        # 800 RoIs: several units per persistent block
+def test_deconv2x2_out1x1_fused_tail(cmid, K, ncls, levels, hw):
     """csrc/deconv_out.hip (MaskSubNet tail, instance.py:196-201,226-233): Conv2DTranspose 2x2 s2 + ReLU -> Conv2D 1x1 +
     sigmoid per RoI level with its own weights, all levels in one launch, written into the image-major
     [B, total, 2h, 2w, ncls] tensor at each level's RoI offset; partly filled 128-pixel tiles at every level end."""
     from masklab_hip import _lib, ops, packing
-    h, w_ = 14, 14
+    h, w_ = hw
     B = levels[0][0]
     total = sum(n for _, n in levels)
     out = torch.full((B, total, 2 * h, 2 * w_, ncls), -7.0, device="cuda")
