@@ -569,3 +569,55 @@ def test_order_stable_fixture_helpers():
     cls[0, 401, 2] = np.float32(0.8) + np.float32(1e-6)         # a near-tie between overlapping neighbours: unstable
     _, same = FX.order_stability(cfg, cls, pri, 0.5, trials=16)
     assert same < 16
+
+
+def test_mobilenet_v1_architecture_vs_transformers_port():
+    """SURVEY 8a row a4 / VERDICT "nothing in the tree pins it": the oracle's MobileNet v1 body (restated from
+    keras-applications, which the reference calls at engine/backbone/base.py:253-258) against an INDEPENDENT
+    implementation -- Hugging Face `transformers.MobileNetV1Model`, a port of the same TF-slim network (TF 'SAME'
+    padding, BN eps 1e-3, ReLU6) -- with the same random weights, at an even input size (where keras'
+    ZeroPadding2D(((0,1),(0,1))) + 'valid' equals TF 'SAME').  Checks block order, strides, widths, which tensors the
+    C1..C5 taps are (conv_pw_1/3/5/11/13), padding side and BN placement."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import MobileNetV1Config, MobileNetV1Model
+    torch.manual_seed(0)
+    hf = MobileNetV1Model(MobileNetV1Config(), add_pooling_layer=False).eval()
+    g = torch.Generator().manual_seed(1)
+    w = {}
+
+    def take(conv_block, name, depthwise):
+        k = conv_block.convolution.weight.detach()
+        with torch.no_grad():                         # He-style scale so activations stay O(1) through 27 layers
+            fan_in = k.shape[1] * k.shape[2] * k.shape[3]
+            k.copy_(torch.randn(k.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+            bn = conv_block.normalization
+            bn.weight.copy_(torch.rand(bn.weight.shape, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(bn.bias.shape, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=g) + 0.5)
+        kn = k.numpy()
+        if depthwise:                                 # torch [C,1,3,3] -> keras depthwise_kernel [3,3,C,1]
+            w[f"{name}/depthwise_kernel"] = np.ascontiguousarray(kn.transpose(2, 3, 0, 1))
+        else:                                         # torch [O,I,kh,kw] -> keras kernel [kh,kw,I,O]
+            w[f"{name}/kernel"] = np.ascontiguousarray(kn.transpose(2, 3, 1, 0))
+        for src, dst in (("weight", "gamma"), ("bias", "beta"), ("running_mean", "moving_mean"),
+                         ("running_var", "moving_variance")):
+            w[f"{name}_bn/{dst}"] = getattr(conv_block.normalization, src).detach().numpy().copy()
+
+    take(hf.conv_stem, "conv1", False)
+    assert len(hf.layer) == 26
+    for i in range(13):
+        take(hf.layer[2 * i], f"conv_dw_{i + 1}", True)
+        take(hf.layer[2 * i + 1], f"conv_pw_{i + 1}", False)
+    x = np.random.default_rng(2).normal(size=(2, 96, 128, 3)).astype(np.float32)
+    taps = O.mobilenet_v1(x.astype(np.float64), w)
+    with torch.no_grad():
+        out = hf(torch.from_numpy(x).permute(0, 3, 1, 2), output_hidden_states=True)
+    hidden = out.hidden_states                       # after each of the 26 layers
+    assert len(hidden) == 26
+    for name, block in (("C1", 1), ("C2", 3), ("C3", 5), ("C4", 11), ("C5", 13)):
+        ref = hidden[2 * block - 1].permute(0, 2, 3, 1).numpy()
+        got = taps[name]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert np.abs(ref).max() > 0.1                # the comparison is not between two all-zero maps
+        np.testing.assert_allclose(got, ref, atol=2e-4, err_msg=name)
