@@ -100,3 +100,15 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["cpu_baseline"] is None
     assert "merged batch 4" in d["config"]["collective"]            # the gather really merged both ranks' images
+
+
+def test_rccl_single_rank_async_gather():
+    """RCCL itself (torch backend 'nccl'), in the one form a one-GPU box allows -- a one-rank communicator: the
+    detection all-gather launched asynchronously on AsyncDetectionGather's stream, three collectives in flight, data
+    back bit-identical (scripts/rccl_single_rank_check.py).  The two-rank paths are covered by gloo tests
+    (tests/test_parallel_cpu.py, test_bench_two_ranks_rehearsal); the driver's 8-GPU run is the first real xGMI exchange."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_single_rank_check.py")],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl single-rank gather: OK" in r.stdout
