@@ -127,7 +127,11 @@ class InferenceModel(K.Layer):
         self.last_detections = None
         self._use_graphs = False
         self._graphs = {}
-        self.use_side_stream = True       # semantic head on a second HIP stream beside FPN / towers / detection
+        # Auxiliary HIP streams (semantic head, box tower, P6/P7, coarse FPN convs beside the main chain): True / False /
+        # "auto" = on unless the forward is so small that it is bound by the host's launch rate, where the extra
+        # stream hand-overs cost more than the overlap gives (1 x 512 x 512: 2.78 ms with, 2.45 ms without); under
+        # hipGraph capture they are always worth it (the branches replay without host work: 1.94 ms).
+        self.use_side_stream = "auto"
         self._side_stream = None
         self._build_shapes()
 
@@ -207,8 +211,8 @@ class InferenceModel(K.Layer):
     def _stage1(self, images, want_kept=False):
         cfg = self.configuration
         bb = self.backbone_network
-        fork_ok = getattr(self, "use_side_stream", False) and self.detection_networks is not None \
-            and hasattr(bb, "join_extra_levels")
+        aux = self._aux_streams_wanted(images)
+        fork_ok = aux and self.detection_networks is not None and hasattr(bb, "join_extra_levels")
         feats = bb(images, fork_stream=self._fork_stream) if fork_ok else bb(images)
         by_name = dict(zip(bb.output_names, feats))
         st = {"image_hw": (int(images.shape[1]), int(images.shape[2]))}
@@ -227,7 +231,7 @@ class InferenceModel(K.Layer):
 
         def launch_semantic_on_side():
             from . import ops as _ops
-            if self.semantic_networks is None or not getattr(self, "use_side_stream", False) or _ops.PROFILE is not None:
+            if self.semantic_networks is None or not aux or _ops.PROFILE is not None:
                 return None
             main = torch.cuda.current_stream()
             if self._side_stream is None:
@@ -252,7 +256,7 @@ class InferenceModel(K.Layer):
             # The class and the box tower are independent chains of the same shape (5 levels x 4 convs, 1365 tiles per
             # launch = 2.67 rounds of the chip's 512 resident blocks): on two streams the last, partly filled round of
             # one launch is topped up by the other tower's blocks.  Same kernels, same inputs: bit-identical outputs.
-            tower_stream = self._fork_stream("_tower_stream") if getattr(self, "use_side_stream", False) else None
+            tower_stream = self._fork_stream("_tower_stream") if aux else None
             if tower_stream is not None:
                 with torch.cuda.stream(tower_stream):
                     st["loc_pred"] = loc_subnet(feature_outputs)
@@ -287,6 +291,14 @@ class InferenceModel(K.Layer):
             # GPU stays busy while the host waits (same stream, same results)
             st["seg_pred"] = semantic_head()
         return st
+
+    def _aux_streams_wanted(self, images):
+        mode = getattr(self, "use_side_stream", False)
+        if mode != "auto":
+            return bool(mode)
+        if torch.cuda.is_current_stream_capturing():
+            return True
+        return int(images.shape[0]) * int(images.shape[1]) * int(images.shape[2]) > 512 * 512
 
     def _fork_stream(self, attr):
         """A lazily created auxiliary stream that starts behind everything enqueued on the current one (None under the
