@@ -151,11 +151,12 @@ deconv_out_kernel(const DoArgs A) {
     };
 
     // ---- LDS: [2 staging buffers: 128 pixel rows + CM weight rows, 128 B each, XOR-swizzled 16-byte groups]
-    //           [1x1 lane table][transposed-conv bias][1x1 bias] of the CURRENT problem
+    //           [1x1 lane table][transposed-conv bias][1x1 bias] of the CURRENT problem [4 wave-private result scratches]
     float *lds_wo = reinterpret_cast<float *>(lds + 2 * BUFB);
     const int n_wo = NT * 16 * 2 * A.cp;
     float *lds_bd = lds_wo + n_wo;
     float *lds_bo = lds_bd + CM;
+    float *lds_scr = lds_bo + 32;                 // 4 waves x [32 pixels][cp] floats
 
     const int ld_row = tid >> 3;
     const int ld_g = (tid & 7) ^ ((ld_row >> 1) & 7);
@@ -228,22 +229,30 @@ deconv_out_kernel(const DoArgs A) {
                 }
             }
 
-        // ---- store: lane = class r, register e = pixel (e & 3) + 8 (e >> 2) + 4 h of this wave's 32
-        if (r < A.ncls) {
-            const DoProb P = prob(cur.pi);            // (selected here, not before the K loop: 26 scalars less to keep alive)
-            const int dy = pos >> 1, dx = pos & 1;
-            const int per_roi = 4 * P.hw * A.ncls;
+        // ---- store.  The result sits as lane = class, register e = pixel (e & 3) + 8 (e >> 2) + 4 h of this wave's 32:
+        // through a wave-private LDS scratch (LDS operations of one wave execute in order: no barrier) it becomes
+        // lane = pixel, so the index arithmetic (three divisions) and the sigmoid run once per pixel and class instead
+        // of 16 times per lane, and a pixel's classes leave as consecutive floats.
+        {
+            float *scr = lds_scr + wave * 32 * A.cp;
+            if (r < A.cp) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int mi = cur.m0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (mi < (int)P.M) {
-                    const int roi = div_small(mi, P.hw, P.r_hw), rem = mi - roi * P.hw;
-                    const int y = div_small(rem, P.w, P.r_w), x = rem - y * P.w;
-                    const int img = div_small(roi, P.n_l, P.r_nl), j = roi - img * P.n_l;
-                    const long long off = (long long)img * P.img_stride + P.base + (long long)j * per_roi +
-                                          (long long)(((2 * y + dy) * 2 * P.w + 2 * x + dx) * A.ncls + r);
-                    const float v = y0[e] + y1[e];
-                    P.out[off] = A.out_sigmoid ? 1.f / (1.f + expf(-v)) : __builtin_amdgcn_fmed3f(v, A.out_lo, A.out_hi);
+                for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * A.cp + r] = y0[e] + y1[e];
+            }
+            const int mi = cur.m0 + 32 * wave + lane;
+            const DoProb P = prob(cur.pi);            // (selected here, not before the K loop: 26 scalars less to keep alive)
+            if (lane < 32 && mi < (int)P.M) {
+                const int dy = pos >> 1, dx = pos & 1;
+                const int per_roi = 4 * P.hw * A.ncls;
+                const int roi = div_small(mi, P.hw, P.r_hw), rem = mi - roi * P.hw;
+                const int y = div_small(rem, P.w, P.r_w), x = rem - y * P.w;
+                const int img = div_small(roi, P.n_l, P.r_nl), j = roi - img * P.n_l;
+                float *dst = P.out + ((long long)img * P.img_stride + P.base + (long long)j * per_roi +
+                                      (long long)(((2 * y + dy) * 2 * P.w + 2 * x + dx) * A.ncls));
+                const float *src = scr + lane * A.cp;
+                for (int c = 0; c < A.ncls; ++c) {
+                    const float v = src[c];
+                    dst[c] = A.out_sigmoid ? 1.f / (1.f + expf(-v)) : __builtin_amdgcn_fmed3f(v, A.out_lo, A.out_hi);
                 }
             }
         }
@@ -257,9 +266,9 @@ deconv_out_kernel(const DoArgs A) {
 template <int NT>
 int launch_do(const DoArgs &A, hipStream_t s) {
     auto kern = deconv_out_kernel<NT>;
-    const int bytes = 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * A.cp + 32 * NT + 32) * 4;
+    const int bytes = 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * A.cp + 32 * NT + 32 + 4 * 32 * A.cp) * 4;
     static std::atomic<unsigned long long> ok{0};
-    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * 32 + 32 * NT + 32) * 4,
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * 32 + 32 * NT + 32 + 4 * 32 * 32) * 4,
                                        ok, "deconv2x2_out1x1"))
         return rc;
     const int units = ((A.tiles + 7) / 8) * 32;          // (tile, position) pairs, tiles rounded up to whole groups of 8
