@@ -205,6 +205,8 @@ def test_hipgraph_replay_equals_eager(bt):
 @pytest.mark.parametrize("bt,shape", [
     ("resnext50", (3, 192, 320, 3)),        # non-square, level sizes 24x40 .. 2x3 (odd at P6/P7)
     ("resnext50", (1, 136, 200, 3)),        # not a multiple of the strides: 'same' ceil sizes 17x25, 9x13, 5x7, 3x4, 2x2
+    ("resnext50", (2, 296, 280, 3)),        # stage-2 maps of 74x70 >= 4096 pixels: the pipelined 1x1 kernel on a ragged M
+                                            # (10 360 rows = 80.9 panels), odd level sizes 37x35, 19x18, 10x9, 5x5, 3x3
     ("mobilenet", (5, 128, 384, 3)),        # odd batch
     ("mobilenet", (32, 128, 128, 3)),       # the MoldBatch maximum (reference misc.py:275)
 ])
