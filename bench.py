@@ -21,8 +21,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   in one step / their summed duration, timed with HIP events on the launch stream in an instrumented
                   step; peak = 157.3 TFLOP/s (fp32 MFMA).  `traffic` comes from a committed PMC pass only when that
                   pass was taken on the kernel sources this library was built from (hash check), else null.
-  cpu_baseline -- the NumPy oracle forward ("port", not TF-Keras) on the host cores: CPU model, BLAS threads, all-core
-                  and 1-thread figures at 1x1024^2 and 1x512^2 (warm-up + median), SURVEY 8(d).
+  cpu_baseline -- the NumPy oracle forward ("port", not TF-Keras) on the host cores: CPU model, BLAS threads, all-core,
+                  8-thread and 1-thread figures at 1x1024^2, all-core and 1-thread at 1x512^2 (warm-up + median),
+                  SURVEY 8(d); `value` = the fastest full-size setting, `cores` = its thread count.
   parity       -- rank 0's first image through the GPU model vs the oracle at full size on an UN-saturated score
                   fixture (oracle/fixtures.py): float outputs within 1e-3, (anchor, class) rows and their ORDER exact.
 """
@@ -207,24 +208,35 @@ def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, img, dev
     first_dt = time.perf_counter() - t0
     thr = internals["min_confidence"]
 
-    # ---- timings: all BLAS threads and 1 thread, full size and 512^2
-    samples = {}
+    # ---- timings: all BLAS threads, 8 threads and 1 thread at full size; all / 1 thread at 512^2.
+    # `value` is the FASTEST full-size figure (the oracle's many small GEMMs do not scale over 64+ BLAS threads: on the
+    # EPYC 9575F box one thread beats all of them), `cores` the thread count it was measured with.
+    samples, threads_of = {}, {}
+    full = f"1x{H}x{W}"
     if quick:
-        samples[f"1x{H}x{W} all threads"] = (first_dt, 1)
+        samples[f"{full} all threads"] = (first_dt, 1)
+        threads_of[f"{full} all threads"] = blas_threads
     else:
-        samples[f"1x{H}x{W} all threads"] = _time_oracle(oracle_forward, 3, 75.0)
+        samples[f"{full} all threads"] = _time_oracle(oracle_forward, 3, 75.0)
+        threads_of[f"{full} all threads"] = blas_threads
+        if blas_threads > 8:
+            with threadpool_limits(limits=8):
+                samples[f"{full} 8 threads"] = _time_oracle(oracle_forward, 1, 1.0)
+            threads_of[f"{full} 8 threads"] = 8
         with threadpool_limits(limits=1):
-            samples[f"1x{H}x{W} 1 thread"] = _time_oracle(oracle_forward, 1, 1.0)
+            samples[f"{full} 1 thread"] = _time_oracle(oracle_forward, 1, 1.0)
+        threads_of[f"{full} 1 thread"] = 1
         if min(H, W) > 512:
             small = np.ascontiguousarray(img[:, :512, :512])
             oracle_forward(small)
             samples["1x512x512 all threads"] = _time_oracle(lambda: oracle_forward(small), 3, 20.0)
             with threadpool_limits(limits=1):
                 samples["1x512x512 1 thread"] = _time_oracle(lambda: oracle_forward(small), 1, 1.0)
-    dt, n_rep = samples[f"1x{H}x{W} all threads"]
-    cpu = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": blas_threads, "kind": "port",
-           "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle-CPU (not TF-Keras), "
-                     f"median of {n_rep} after 1 warm-up, {dt:.1f}s each",
+    best = min((k for k in samples if k.startswith(full)), key=lambda k: samples[k][0])
+    dt, n_rep = samples[best]
+    cpu = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads_of[best], "kind": "port",
+           "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle-CPU (not TF-Keras), fastest thread "
+                     f"setting ({best.split(' ', 1)[1]}), median of {n_rep} after 1 warm-up, {dt:.1f}s each",
            "cpu_model": _cpu_model(), "host_cores": cores, "blas_threads": blas_threads,
            "images_per_sec": {k: round(1.0 / v[0], 4) for k, v in samples.items()},
            "seconds": {k: round(v[0], 2) for k, v in samples.items()}}
