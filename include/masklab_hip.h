@@ -15,9 +15,11 @@
  *     write a slice of a concat buffer without a copy);
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work;
  *   - return value: 0 = ok, negative = ML_E_* (no exceptions cross the boundary);
- *   - thread-safe per stream; the only global state is the per-thread error string and, per
- *     kernel, an atomic bitmask of the devices whose dynamic-LDS limit has been raised
- *     (hipFuncSetAttribute is a per-device setting; racing threads set the same value).
+ *   - thread-safe per stream; the only global state is the per-thread error string, per
+ *     kernel an atomic bitmask of the devices whose dynamic-LDS limit has been raised
+ *     (hipFuncSetAttribute is a per-device setting; racing threads set the same value), and
+ *     a per-device cache of the compute-unit count (sizes the persistent kernels' grids;
+ *     never changes what is computed).
  */
 #ifndef MASKLAB_HIP_H
 #define MASKLAB_HIP_H

@@ -58,3 +58,21 @@ static inline int ml_ensure_dynamic_lds(const void *fn, int bytes, std::atomic<u
     done.fetch_or(bit, std::memory_order_release);
     return ML_OK;
 }
+
+// Blocks a persistent kernel keeps resident: `per_cu` per compute unit of the CURRENT device, rounded down to a
+// multiple of 32 (the persistent kernels map work units to blocks modulo small powers of two), at least 32.  The
+// CU count is read once per device (256 on MI355X in SPX mode; fewer in partitioned modes).  Only scheduling depends on
+// it, never which values are computed or in which order.
+static inline int ml_resident_blocks(int per_cu) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256 * per_cu;
+    int n = cus[dev].load(std::memory_order_acquire);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_release);
+    }
+    const int r = n * per_cu / 32 * 32;
+    return r < 32 ? 32 : r;
+}
+

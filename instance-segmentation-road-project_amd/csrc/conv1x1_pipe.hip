@@ -503,7 +503,7 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     A.NB = d.cout / BN;
     // enough work units to fill every resident block (2 per CU), and at most PIPE_MAX_NBG N tiles per block: split a
     // panel's N tiles into 2^gshift groups
-    const int resident = 512;
+    const int resident = ml_resident_blocks(2);          // two 4-wave blocks per CU (512 on MI355X)
     // Split a panel's N tiles into 2^gshift groups (a unit = one group of one panel).  Blocks are persistent and take
     // units round-robin, so the launch lasts ceil(units / resident) units: pick the split whose last round is fullest
     // (800 panels: 1 group -> 2 rounds for 1.56 rounds of work, 4 groups -> 7 for 6.25), the coarser one on a near tie

@@ -272,7 +272,7 @@ int launch_do(const DoArgs &A, hipStream_t s) {
                                        ok, "deconv2x2_out1x1"))
         return rc;
     const int units = ((A.tiles + 7) / 8) * 32;          // (tile, position) pairs, tiles rounded up to whole groups of 8
-    const int resident = NT <= 4 ? 512 : 256;            // 2 / 1 blocks per CU
+    const int resident = ml_resident_blocks(NT <= 4 ? 2 : 1);
     const int grid = units < resident ? units : resident;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, s, A);
     ML_CHECK_LAUNCH("deconv2x2_out1x1");
