@@ -26,7 +26,10 @@
 //   few tiles but a long K can be split along K: slices write raw partial tiles to a workspace
 //   slab and a second kernel reduces them in a FIXED order (deterministic, no atomics).
 //   Block -> tile map is XCD aware: the NB column tiles that share one 128-pixel A panel get
-//   ids congruent mod 8, i.e. the same XCD / L2.
+//   ids congruent mod 8, i.e. the same XCD / L2; for spatial (3x3 ...) convs each XCD additionally takes a
+//   CONTIGUOUS range of panels, so the halo rows two neighbouring panels share are fetched into one L2.
+//   1x1 convs with K <= 512 on maps of >= 64x64 pixels go to the persistent pipelined kernel (conv1x1_pipe.hip)
+//   instead; activations >= 2 GiB are cut into image groups (split_by_image_groups below).
 #include "common.h"
 
 
