@@ -104,6 +104,10 @@ int ml_conv2d_multi_f32(const ml_conv2d_desc *descs, int32_t n, void *workspace,
                         void *stream);
 /* N-tile width the auto heuristic picks for `cout` (host packs n_pad from it). */
 int ml_conv2d_ntile(int32_t cout, int32_t tile);
+/* N-tile width (128 / 64 / 32) of the generic implicit-GEMM kernel that ml_conv2d_multi_f32 will run for these
+ * problems: launches too small to fill the chip with 128-wide tiles run on narrower ones (bit-identical results:
+ * same k-ordered chains, split-K cut at the same k).  For reporting only; 0 on bad arguments. */
+int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace);
 /* 1 when ml_conv2d_multi_f32 runs this single problem on the persistent, tile-pipelined 1x1 kernel
  * (conv1x1_pipe.hip: the short-K bottleneck convs of engine/backbone/ResNext.py:199-231), else 0. */
 int ml_conv2d_uses_pipe(const ml_conv2d_desc *d);

@@ -673,8 +673,11 @@ int choose_splits(long long tiles, int chunks) {
     return s < 2 ? 1 : s;
 }
 
+// split_tiles >= 0: the tile count the split-K decision is taken on (see narrow_tile_for_small_launch), else this
+// launch's own
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool F16>
-int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s) {
+int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s,
+                 long long split_tiles = -1) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : 2 * (BM + BN) * LDS_LD * 4;
@@ -694,6 +697,7 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
         launch_tiles += ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
     }
+    if (split_tiles >= 0) launch_tiles = split_tiles;
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
         Problem &P = args.p[i];
@@ -802,6 +806,37 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
     return m;
 }
 
+// A launch that cannot fill the chip with 128-wide tiles (small batches: one 512x512 image gives the towers 43 tiles)
+// is bound by ONE tile's K loop -- 2 us per 32-deep chunk.  With 32- (or 64-) wide tiles the same launch is 4 (2) times
+// as many blocks whose chunks take a quarter (half) of the matrix time.  Results are bit-identical: every output is the
+// same k-ordered chain whatever the tile shape, and the split-K decision is still taken on the 128-wide tile count, so
+// the partial sums are cut at the same k.  -> tile code to use (t0 = keep) and that tile count.
+static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int t0, bool have_ws, long long *ref_tiles) {
+    *ref_tiles = -1;
+    if (t0 == 3) return t0;
+    const int ref_bn = t0 == 1 ? 128 : 64;
+    long long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].group_cin_step) return t0;
+        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
+        tiles += ((M + 127) / 128) * (descs[i].n_pad / ref_bn);
+    }
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ml_conv2d_desc &d = descs[i];
+        const long long M = (long long)d.B * d.Ho * d.Wo;
+        const int chunks = d.KH * d.KW * (d.span_pad / 32);
+        const int splits = (have_ws && !d.out_f16) ? choose_splits(tiles, chunks) : 1;
+        blocks += ((M + 127) / 128) * (d.n_pad / ref_bn) * splits;
+    }
+    const long long resident = ml_resident_blocks(2);
+    *ref_tiles = tiles;
+    if (blocks * (ref_bn / 32) <= resident) return 3;
+    if (ref_bn == 128 && blocks * 2 <= resident) return 2;
+    *ref_tiles = -1;
+    return t0;
+}
+
 extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in, void *workspace, int64_t workspace_bytes,
                                    void *stream) {
     ML_REQUIRE(descs_in != nullptr && n_in >= 1 && n_in <= MAXP, "conv2d: need 1..%d problems", MAXP);
@@ -838,18 +873,30 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    long long ref_tiles = -1;
+    const int t = narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles);
     if (descs[0].math == ML_MATH_F16) {
-        switch (t0) {
-            case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s);
-            case 2: return launch_multi<2, 2, 2, 1, true>(descs, n, workspace, workspace_bytes, s);
-            default: return launch_multi<4, 1, 1, 1, true>(descs, n, workspace, workspace_bytes, s);
+        switch (t) {
+            case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 2: return launch_multi<2, 2, 2, 1, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            default: return launch_multi<4, 1, 1, 1, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         }
     }
-    switch (t0) {
-        case 1: return launch_multi<2, 2, 2, 2, false>(descs, n, workspace, workspace_bytes, s);
-        case 2: return launch_multi<2, 2, 2, 1, false>(descs, n, workspace, workspace_bytes, s);
-        default: return launch_multi<4, 1, 1, 1, false>(descs, n, workspace, workspace_bytes, s);
+    switch (t) {
+        case 1: return launch_multi<2, 2, 2, 2, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        case 2: return launch_multi<2, 2, 2, 1, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        default: return launch_multi<4, 1, 1, 1, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
     }
+}
+
+// N-tile width (128 / 64 / 32) the generic kernel will use for this launch (after the small-launch narrowing); 0 on bad
+// arguments.  For reporting: which kernel instantiation a launch's time belongs to.
+extern "C" int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace) {
+    if (!descs || n < 1 || n > MAXP) return 0;
+    const int t0 = pick_tile(descs[0].cout, descs[0].tile);
+    long long ref_tiles = -1;
+    const int t = narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles);
+    return t == 1 ? 128 : (t == 2 ? 64 : 32);
 }
 
 extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {

@@ -183,9 +183,14 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     return d, ret, (2.0 * M * p.cout * p.k_real, nbytes, shape)
 
 
-def _conv_kernel_name(p):
-    return "conv_mfma_128x%d%s%s" % (_lib.load().ml_conv2d_ntile(p.cout, p.tile),
-                                     "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH != "f32" else "")
+def _conv_kernel_name(p, descs=None, n=1):
+    """Name of the kernel instantiation a launch runs on (profiling hook only).  With the descriptors the library is
+    asked which N tile it will really use: small launches run on narrower tiles than the weights were packed for."""
+    lib = _lib.load()
+    bn = lib.ml_conv2d_launch_ntile(descs, n, 1) if descs is not None and PROFILE is not None else 0
+    if not bn:
+        bn = lib.ml_conv2d_ntile(p.cout, p.tile)
+    return "conv_mfma_128x%d%s%s" % (bn, "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH != "f32" else "")
 
 
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
@@ -202,7 +207,7 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
                                                 in_coff, out_view, out_dtype)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
-    name = _conv_kernel_name(dc.p)
+    name = _conv_kernel_name(dc.p, C.byref(d), 1)
     if PROFILE is not None and lib.ml_conv2d_uses_pipe(C.byref(d)):
         name = "conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe"
     with _Prof(name, flops, nbytes, shape):
@@ -228,7 +233,7 @@ def conv2d_multi(problems):
         rets.append(ret)
         flops += f
         nbytes += nb
-    name = _conv_kernel_name(problems[0]["dc"].p)
+    name = _conv_kernel_name(problems[0]["dc"].p, arr, n)
     ws = workspace(int(lib.ml_conv2d_workspace_bytes()), problems[0]["x"].device, "conv")
     with _Prof(name, flops, nbytes, f"multi x{n}"):
         _lib.check(lib.ml_conv2d_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
