@@ -390,3 +390,36 @@ def test_out1x1_lane_table_reproduces_the_1x1_conv():
         packing.pack_out1x1_table(np.zeros((1, 1, 128, 33), np.float32))
     with pytest.raises(ValueError):
         packing.pack_out1x1_table(np.zeros((1, 1, 100, 3), np.float32))
+
+
+def test_small_launches_pick_narrow_tiles():
+    """ml_conv2d_launch_ntile (host logic only, no GPU needed): a launch whose 128-wide tiles x K splits cannot fill the
+    resident blocks runs on 128x32 (x4 <= 512) or 128x64 (x2 <= 512) tiles; big launches, grouped convs and launches
+    packed for 32-wide tiles keep theirs.  The split-K count is taken from the 128-wide tile count either way."""
+    from masklab_hip import _lib
+    lib = _lib.load()
+
+    def desc(B, H, W, cin, cout, k=3, group_step=0, tile=0):
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
+        d.in_cstride, d.in_coff, d.span, d.span_pad, d.cpp_shift = cin, 0, cin, -(-cin // 32) * 32, 30
+        d.KH = d.KW = k
+        d.stride = d.dil = 1
+        d.cout, d.n_pad, d.out_cstride = cout, -(-cout // 128) * 128, cout
+        d.group_cin_step, d.tile, d.math = group_step, tile, 0
+        return d
+
+    def ntile(ds, ws=1):
+        arr = (_lib.ConvDesc * len(ds))(*ds)
+        return lib.ml_conv2d_launch_ntile(arr, len(ds), ws)
+
+    assert ntile([desc(8, 128, 128, 128, 128)]) == 128                 # 1024 tiles: fills the chip
+    assert ntile([desc(1, 64, 64, 128, 128)]) == 32                    # 32 tiles x 4 splits = 128 blocks -> x4 = 512
+    assert ntile([desc(1, 64, 64, 128, 128)], ws=0) == 32              # no workspace: no split-K, 32 tiles
+    assert ntile([desc(2, 64, 64, 128, 128)]) == 64                    # 64 tiles x 4 splits = 256 blocks: x2 fits, x4 not
+    assert ntile([desc(4, 64, 64, 128, 128)]) == 128                   # 128 tiles x 4 splits = 512 blocks
+    levels = [desc(1, s, s, 128, 128) for s in (64, 32, 16, 8, 4)]     # the five tower levels of one 512x512 image
+    assert ntile(levels) == 64                                         # 44 tiles x 4 splits = 176 blocks: x2 fits, x4 not
+    assert ntile([desc(1, 16, 16, 1024, 1024, k=3, group_step=32, tile=3)]) == 32    # grouped: packed for 32 already
+    assert ntile([desc(1, 64, 64, 128, 48)]) == 32                     # cout <= 96 picks 32 / 64 by itself
+    assert lib.ml_conv2d_launch_ntile(None, 1, 1) == 0
