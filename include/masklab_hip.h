@@ -345,6 +345,16 @@ int64_t ml_instance_summary_workspace_bytes(int32_t B, int32_t H);
 int ml_instance_summary_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const float *masks,
                             float *out5, int32_t B, int32_t n, int32_t H, int32_t W, float default_road_size,
                             float ioi_threshold, void *workspace, void *stream);
+/* The same numbers WITHOUT the padded canvases: CropAndPadMask (misc.py:358-401) and SummaryOutput's arithmetic
+ * (:574-589) in one pass.  det [B,n,6] int32 and roi_masks [B,n,mh,mw] int32 are CropAndPadMask's inputs; every canvas
+ * value is recomputed on the fly with that layer's arithmetic and only the rows / columns a box covers are visited
+ * (what is skipped is exactly zero), so out5 is bit-identical to ml_crop_pad_mask_f32 followed by
+ * ml_instance_summary_f32 while the [B,n,H,W] tensor (3.4 GB at 8 x 100 x 1024^2) is never written or read.
+ * Same workspace size as ml_instance_summary_f32.                                                        */
+int ml_instance_summary_rois_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const int32_t *det,
+                                 const int32_t *roi_masks, float *out5, int32_t B, int32_t n, int32_t mh, int32_t mw,
+                                 int32_t H, int32_t W, float default_road_size, float ioi_threshold, void *workspace,
+                                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -248,6 +248,38 @@ __global__ void __launch_bounds__(256) conf_threshold_kernel(const int32_t *__re
     if (threadIdx.x == 0) *thr = red[0] > 50 ? 50 : -100;
 }
 
+// Where CropAndPadMask pastes an instance (misc.py:377-398): box = max(box, 1) elementwise, corners ceil(c -+ size/2)
+// clipped to the canvas; rows below the confidence threshold and zero-sized boxes paste nothing (empty box).
+struct PasteBox {
+    int xmin, xmax, ymin, ymax;      // [xmin, xmax) x [ymin, ymax); empty when nothing is pasted
+    float sy, sx;                    // mask rows / columns per canvas row / column (align_corners)
+};
+__device__ __forceinline__ PasteBox paste_box(const int32_t *d, int thr, int mh, int mw, int H, int W) {
+    PasteBox p = {0, 0, 0, 0, 0.f, 0.f};
+    if (d[5] < thr) return p;
+    const float cx = (float)max(d[0], 1), cy = (float)max(d[1], 1), w = (float)max(d[2], 1), h = (float)max(d[3], 1);
+    p.xmin = min(max((int)ceilf(cx - w / 2.f), 0), W); p.xmax = min(max((int)ceilf(cx + w / 2.f), 0), W);
+    p.ymin = min(max((int)ceilf(cy - h / 2.f), 0), H); p.ymax = min(max((int)ceilf(cy + h / 2.f), 0), H);
+    const int oh = p.ymax - p.ymin, ow = p.xmax - p.xmin;
+    p.sy = oh > 1 ? (float)(mh - 1) / (float)(oh - 1) : 0.f;
+    p.sx = ow > 1 ? (float)(mw - 1) / (float)(ow - 1) : 0.f;
+    if (oh <= 0 || ow <= 0) p.xmax = p.xmin = p.ymax = p.ymin = 0;
+    return p;
+}
+// value of canvas pixel (y, x): the mh x mw int mask resized bilinear (align_corners) to the box; 0 outside it
+__device__ __forceinline__ float paste_value(const PasteBox &p, const int32_t *m, int mh, int mw, int y, int x) {
+    if (!(y >= p.ymin && y < p.ymax && x >= p.xmin && x < p.xmax)) return 0.f;
+    const float fy = (float)(y - p.ymin) * p.sy, fx = (float)(x - p.xmin) * p.sx;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int y0 = max((int)fly, 0), x0 = max((int)flx, 0);
+    const int y1 = min((int)ceilf(fy), mh - 1), x1 = min((int)ceilf(fx), mw - 1);
+    const float ty = fy - fly, tx = fx - flx;
+    const float tl = (float)m[y0 * mw + x0], tr = (float)m[y0 * mw + x1];
+    const float bl = (float)m[y1 * mw + x0], br = (float)m[y1 * mw + x1];
+    const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+    return top + (bot - top) * ty;
+}
+
 // out[b,i,y,x]: the mh x mw mask of a selected instance resized (bilinear, align_corners) to its box and
 // placed at (ymin, xmin) of an H x W canvas of zeros (misc.py:377-398).  One thread per canvas pixel.
 __global__ void crop_pad_mask_kernel(const int32_t *__restrict__ det, const int32_t *__restrict__ masks,
@@ -259,46 +291,48 @@ __global__ void crop_pad_mask_kernel(const int32_t *__restrict__ det, const int3
     long long t = idx / W;
     const int y = (int)(t % H);
     const long long row = t / H;                 // b * n + i
-    const int32_t *d = det + row * 6;
-    float v = 0.f;
-    if (d[5] >= *thr) {
-        // box = max(box, 1) elementwise, then float (misc.py:378-382)
-        const float cx = (float)max(d[0], 1), cy = (float)max(d[1], 1), w = (float)max(d[2], 1), h = (float)max(d[3], 1);
-        const int xmin = min(max((int)ceilf(cx - w / 2.f), 0), W), xmax = min(max((int)ceilf(cx + w / 2.f), 0), W);
-        const int ymin = min(max((int)ceilf(cy - h / 2.f), 0), H), ymax = min(max((int)ceilf(cy + h / 2.f), 0), H);
-        const int oh = ymax - ymin, ow = xmax - xmin;
-        if (y >= ymin && y < ymax && x >= xmin && x < xmax) {      // (a zero-sized box pastes nothing)
-            const float sy = oh > 1 ? (float)(mh - 1) / (float)(oh - 1) : 0.f;
-            const float sx = ow > 1 ? (float)(mw - 1) / (float)(ow - 1) : 0.f;
-            const float fy = (float)(y - ymin) * sy, fx = (float)(x - xmin) * sx;
-            const float fly = floorf(fy), flx = floorf(fx);
-            const int y0 = max((int)fly, 0), x0 = max((int)flx, 0);
-            const int y1 = min((int)ceilf(fy), mh - 1), x1 = min((int)ceilf(fx), mw - 1);
-            const float ty = fy - fly, tx = fx - flx;
-            const int32_t *m = masks + row * mh * mw;
-            const float tl = (float)m[y0 * mw + x0], tr = (float)m[y0 * mw + x1];
-            const float bl = (float)m[y1 * mw + x0], br = (float)m[y1 * mw + x1];
-            const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
-            v = top + (bot - top) * ty;
-        }
-    }
-    out[idx] = v;
+    const PasteBox p = paste_box(det + row * 6, *thr, mh, mw, H, W);
+    out[idx] = paste_value(p, masks + row * mh * mw, mh, mw, y, x);
 }
 
 // ---- CrackToInstance (misc.py:524-551): bounding box of the non-zero pixels of a [B,H,W] int32 map over the
 // WHOLE batch (the reference reduces tf.where over all rows).  box = {ymin, xmin, ymax, xmax, any}
-__global__ void nonzero_bbox_kernel(const int32_t *__restrict__ map, int cstride, int coff, int H, int W, long long total,
-                                    int32_t *__restrict__ box) {
-    const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (idx >= total) return;
-    if (map[idx * cstride + coff] != 0) {
-        const int x = (int)(idx % W);
-        const int y = (int)((idx / W) % H);
-        atomicMin(&box[0], y);
-        atomicMin(&box[1], x);
-        atomicMax(&box[2], y);
-        atomicMax(&box[3], x);
-        box[4] = 1;
+constexpr int BBOX_EPT = 8;                  // elements per thread
+__global__ void __launch_bounds__(TPB) nonzero_bbox_kernel(const int32_t *__restrict__ map, int cstride, int coff, int H, int W,
+                                                           long long total, int32_t *__restrict__ box) {
+    // (a map that is mostly non-zero -- the crack channel of a random-weight model -- used to mean one atomic quartet per
+    // pixel on four addresses: 2.8 ms at 8 x 1024^2; now one per block of 2048 pixels)
+    __shared__ int red[4][TPB / 64];
+    int y0 = 0x7fffffff, x0 = 0x7fffffff, y1 = -1, x1 = -1;
+    const long long base = (long long)blockIdx.x * (TPB * BBOX_EPT) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < BBOX_EPT; ++k) {
+        const long long idx = base + (long long)k * TPB;
+        if (idx < total && map[idx * cstride + coff] != 0) {
+            const int x = (int)(idx % W);
+            const int y = (int)((idx / W) % H);
+            y0 = min(y0, y); x0 = min(x0, x); y1 = max(y1, y); x1 = max(x1, x);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        y0 = min(y0, __shfl_down(y0, off, 64)); x0 = min(x0, __shfl_down(x0, off, 64));
+        y1 = max(y1, __shfl_down(y1, off, 64)); x1 = max(x1, __shfl_down(x1, off, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = y0; red[1][wave] = x0; red[2][wave] = y1; red[3][wave] = x1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) {
+            y0 = min(y0, red[0][w]); x0 = min(x0, red[1][w]); y1 = max(y1, red[2][w]); x1 = max(x1, red[3][w]);
+        }
+        if (y1 >= 0) {
+            atomicMin(&box[0], y0);
+            atomicMin(&box[1], x0);
+            atomicMax(&box[2], y1);
+            atomicMax(&box[3], x1);
+            box[4] = 1;
+        }
     }
 }
 
@@ -416,24 +450,50 @@ __global__ void __launch_bounds__(256) road_unit_length_kernel(const int32_t *__
     }
 }
 
+// Mask source of the summary kernels: the padded canvas CropAndPadMask wrote (ROI = false: [B,n,H,W] floats, read in
+// full), or the un-pasted instances themselves (ROI = true: detections + mh x mw int masks + the confidence threshold):
+// the canvas value is recomputed on the fly (paste_value: the same arithmetic, bit for bit) and only the rows / column
+// stripes that meet the box are visited -- every row keeps its wave and every pixel its lane, and what is skipped is
+// exactly zero, so the sums are bit-identical while 3.4 GB (8 x 100 canvases of 1024^2) are never written or read.
+struct RoiSrc {
+    const int32_t *det, *masks, *thr;
+    int mh, mw;
+};
+
 // per (instance, image): rows are dealt to the 4 waves, lanes sweep x.  out5 = {pixel sum, instance size,
 // (horizontal: second kernel), vertical size, include_my_road}
-__global__ void __launch_bounds__(256) instance_rows_kernel(const float *__restrict__ masks, const int32_t *__restrict__ seg,
+template <bool ROI>
+__global__ void __launch_bounds__(256) instance_rows_kernel(const float *__restrict__ masks, RoiSrc R,
+                                                            const int32_t *__restrict__ seg,
                                                             int cstride, int road_coff, const float *__restrict__ unit, int n,
-                                                            int H, int W, float ioi_threshold, float *__restrict__ out5) {
+                                                            int H, int W, float ioi_threshold, float *__restrict__ out5,
+                                                            int S, double *__restrict__ part) {
     __shared__ double red[5][4];
     const int i = blockIdx.x, b = blockIdx.y;
+    // S > 1 (few instances: the crack pseudo-instance is ONE canvas per image): blockIdx.z owns a band of image rows --
+    // a multiple of 4, so every row keeps its wave -- and leaves its five partial sums for instance_rows_finish_kernel
+    const int band = ((H + S - 1) / S + 3) / 4 * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *m = masks + ((long long)(b * n + i) * H) * W;
+    const float *m = ROI ? nullptr : masks + ((long long)(b * n + i) * H) * W;
     const int32_t *road = seg + ((long long)b * H * W) * cstride + road_coff;
+    PasteBox pb = {0, W, 0, H, 0.f, 0.f};
+    const int32_t *mi = nullptr;
+    if (ROI) {
+        pb = paste_box(R.det + (long long)(b * n + i) * 6, *R.thr, R.mh, R.mw, H, W);
+        mi = R.masks + (long long)(b * n + i) * R.mh * R.mw;
+    }
+    // first row of this wave inside the box (and the band), first column stripe that meets it (ROI = false: everything)
+    const int ylo = max(pb.ymin, (int)blockIdx.z * band), yhi = min(pb.ymax, ((int)blockIdx.z + 1) * band);
+    const int y_first = ylo + ((wave - ylo) % 4 + 4) % 4;
+    const int x_first = (pb.xmin / 64) * 64 + lane;
     double pix = 0, size = 0, vert = 0, inter = 0, area = 0;
-    for (int y = wave; y < H; y += 4) {
+    for (int y = y_first; y < yhi; y += 4) {
         const float u = unit[b * H + y];
         float rs = 0.f;
         int rin = 0, rar = 0;
         bool any = false;
-        for (int x = lane; x < W; x += 64) {
-            const float v = m[(long long)y * W + x];
+        for (int x = x_first; x < pb.xmax; x += 64) {
+            const float v = ROI ? paste_value(pb, mi, R.mh, R.mw, y, x) : m[(long long)y * W + x];
             rs += v;
             const bool on = v > 0.5f;
             any |= on;
@@ -457,6 +517,10 @@ __global__ void __launch_bounds__(256) instance_rows_kernel(const float *__restr
     if (threadIdx.x == 0) {
         double t[5];
         for (int k = 0; k < 5; ++k) t[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+        if (S > 1) {
+            for (int k = 0; k < 5; ++k) part[((long long)(b * n + i) * S + blockIdx.z) * 5 + k] = t[k];
+            return;
+        }
         float *o = out5 + (long long)(b * n + i) * 5;
         o[0] = (float)t[0];
         o[1] = (float)t[1];
@@ -466,23 +530,91 @@ __global__ void __launch_bounds__(256) instance_rows_kernel(const float *__restr
     }
 }
 
-// horizontal size = max over x of sum_y unit[y] * mask[y, x] (misc.py:656-658): threads own columns
-__global__ void __launch_bounds__(256) instance_cols_kernel(const float *__restrict__ masks, const float *__restrict__ unit,
-                                                            int n, int H, int W, float *__restrict__ out5) {
+// S > 1: the bands' partial sums in band order, then the same five outputs; the column maxima of the column slices
+__global__ void instance_finish_kernel(const double *__restrict__ part, const float *__restrict__ cmax, int S, int total,
+                                       float ioi_threshold, float *__restrict__ out5) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total) return;
+    double t[5] = {0, 0, 0, 0, 0};
+    float best = -INFINITY;
+    for (int z = 0; z < S; ++z) {
+        for (int k = 0; k < 5; ++k) t[k] += part[((long long)r * S + z) * 5 + k];
+        best = fmaxf(best, cmax[(long long)r * S + z]);
+    }
+    float *o = out5 + (long long)r * 5;
+    o[0] = (float)t[0];
+    o[1] = (float)t[1];
+    o[2] = best;
+    o[3] = (float)t[2];
+    const float ioi = (float)t[3] / ((float)t[4] + 1e-5f);
+    o[4] = ioi > ioi_threshold ? 1.f : 0.f;
+}
+
+// horizontal size = max over x of sum_y unit[y] * mask[y, x] (misc.py:656-658): threads own columns.  ROI: columns
+// outside the box sum to exactly 0 (one of them is accounted for when the box leaves any), rows outside add exactly 0.
+template <bool ROI>
+__global__ void __launch_bounds__(256) instance_cols_kernel(const float *__restrict__ masks, RoiSrc R,
+                                                            const float *__restrict__ unit,
+                                                            int n, int H, int W, float *__restrict__ out5, int S,
+                                                            float *__restrict__ cmax) {
     __shared__ float red[4];
     const int i = blockIdx.x, b = blockIdx.y;
-    const float *m = masks + ((long long)(b * n + i) * H) * W;
+    const int cband = ((W + S - 1) / S + 255) / 256 * 256;     // S > 1: blockIdx.z owns a band of columns (multiple of 256)
+    const float *m = ROI ? nullptr : masks + ((long long)(b * n + i) * H) * W;
+    PasteBox pb = {0, W, 0, H, 0.f, 0.f};
+    const int32_t *mi = nullptr;
+    if (ROI) {
+        pb = paste_box(R.det + (long long)(b * n + i) * 6, *R.thr, R.mh, R.mw, H, W);
+        mi = R.masks + (long long)(b * n + i) * R.mh * R.mw;
+    }
     float best = -INFINITY;
-    for (int x = threadIdx.x; x < W; x += 256) {
+    if (ROI && threadIdx.x == 0 && (pb.xmax - pb.xmin < W)) best = 0.f;      // a column the box does not reach
+    const int xlo = max(pb.xmin, (int)blockIdx.z * cband), xhi = min(pb.xmax, ((int)blockIdx.z + 1) * cband);
+    for (int x = (xlo / 256) * 256 + threadIdx.x; x < xhi; x += 256) {
         float s = 0.f;
-        for (int y = 0; y < H; ++y) s += unit[b * H + y] * m[(long long)y * W + x];
+        if (ROI) {
+            if (x >= pb.xmin)
+                for (int y = pb.ymin; y < pb.ymax; ++y) s += unit[b * H + y] * paste_value(pb, mi, R.mh, R.mw, y, x);
+        } else {
+            for (int y = 0; y < H; ++y) s += unit[b * H + y] * m[(long long)y * W + x];
+        }
         best = fmaxf(best, s);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
     __syncthreads();
-    if (threadIdx.x == 0) out5[(long long)(b * n + i) * 5 + 2] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        const float v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (S > 1) cmax[(long long)(b * n + i) * S + blockIdx.z] = v;
+        else out5[(long long)(b * n + i) * 5 + 2] = v;
+    }
+}
+
+// slices per instance for the summary kernels: one block per (instance, image) fills the chip from ~128 blocks on;
+// below that the rows / columns of an instance are cut into up to 32 bands
+static int summary_slices(int B, int n) {
+    const int blocks = B * n;
+    if (blocks >= 128) return 1;
+    const int s = 256 / blocks;
+    return s > 32 ? 32 : (s < 1 ? 1 : s);
+}
+constexpr long long SUMMARY_PART_BYTES = 128 * 32 * (5 * 8 + 4) + 64;      // partial sums + column maxima of < 128 x 32 slices
+
+template <bool ROI>
+static int launch_summary(const float *masks, const RoiSrc &R, const int32_t *seg, int seg_channels, int road_channel,
+                          const float *unit, void *part_ws, int B, int n, int H, int W, float ioi_threshold, float *out5,
+                          hipStream_t s) {
+    const int S = summary_slices(B, n);
+    double *part = reinterpret_cast<double *>(part_ws);
+    float *cmax = reinterpret_cast<float *>(part + (size_t)B * n * S * 5);
+    hipLaunchKernelGGL(instance_rows_kernel<ROI>, dim3(n, B, S), dim3(256), 0, s, masks, R, seg, seg_channels, road_channel, unit,
+                       n, H, W, ioi_threshold, out5, S, part);
+    hipLaunchKernelGGL(instance_cols_kernel<ROI>, dim3(n, B, S), dim3(256), 0, s, masks, R, unit, n, H, W, out5, S, cmax);
+    if (S > 1)
+        hipLaunchKernelGGL(instance_finish_kernel, dim3((B * n + 63) / 64), dim3(64), 0, s, part, cmax, S, B * n, ioi_threshold,
+                           out5);
+    return ML_OK;
 }
 
 }  // namespace
@@ -505,14 +637,15 @@ extern "C" int ml_nonzero_bbox_i32(const int32_t *map, int32_t B, int32_t H, int
                                    int32_t *box5, void *stream) {
     ML_REQUIRE(map && box5 && B > 0 && H > 0 && W > 0 && cstride > 0 && coff >= 0 && coff < cstride, "nonzero_bbox: bad arguments");
     const long long total = (long long)B * H * W;
-    hipLaunchKernelGGL(nonzero_bbox_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, map, cstride, coff, H, W,
-                       total, box5);
+    hipLaunchKernelGGL(nonzero_bbox_kernel, dim3(grid_for((total + BBOX_EPT - 1) / BBOX_EPT)), dim3(TPB), 0, (hipStream_t)stream,
+                       map, cstride, coff, H, W, total, box5);
     ML_CHECK_LAUNCH("nonzero_bbox");
     return ML_OK;
 }
 
 extern "C" int64_t ml_instance_summary_workspace_bytes(int32_t B, int32_t H) {
-    return ((int64_t)B * H * 2 + B) * (int64_t)sizeof(int32_t) + (int64_t)B * H * (int64_t)sizeof(float) + 256;
+    return ((int64_t)B * H * 2 + B) * (int64_t)sizeof(int32_t) + (int64_t)B * H * (int64_t)sizeof(float) + 256 +
+           SUMMARY_PART_BYTES;
 }
 
 extern "C" int ml_instance_summary_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const float *masks,
@@ -530,9 +663,34 @@ extern "C" int ml_instance_summary_f32(const int32_t *seg, int32_t seg_channels,
     hipLaunchKernelGGL(road_row_extent_kernel, dim3(H, B), dim3(64), 0, s, seg, seg_channels, road_channel, H, W, xmin, xmax,
                        last_row);
     hipLaunchKernelGGL(road_unit_length_kernel, dim3(B), dim3(256), 0, s, xmin, xmax, last_row, H, default_road_size, unit);
-    hipLaunchKernelGGL(instance_rows_kernel, dim3(n, B), dim3(256), 0, s, masks, seg, seg_channels, road_channel, unit, n, H, W,
-                       ioi_threshold, out5);
-    hipLaunchKernelGGL(instance_cols_kernel, dim3(n, B), dim3(256), 0, s, masks, unit, n, H, W, out5);
+    const RoiSrc none = {nullptr, nullptr, nullptr, 0, 0};
+    void *part_ws = reinterpret_cast<char *>(workspace) + (ml_instance_summary_workspace_bytes(B, H) - SUMMARY_PART_BYTES) / 8 * 8;
+    launch_summary<false>(masks, none, seg, seg_channels, road_channel, unit, part_ws, B, n, H, W, ioi_threshold, out5, s);
     ML_CHECK_LAUNCH("instance_summary");
+    return ML_OK;
+}
+
+extern "C" int ml_instance_summary_rois_f32(const int32_t *seg, int32_t seg_channels, int32_t road_channel, const int32_t *det,
+                                            const int32_t *roi_masks, float *out5, int32_t B, int32_t n, int32_t mh, int32_t mw,
+                                            int32_t H, int32_t W, float default_road_size, float ioi_threshold, void *workspace,
+                                            void *stream) {
+    ML_REQUIRE(seg && det && roi_masks && out5 && workspace, "instance_summary_rois: null pointer");
+    ML_REQUIRE(B > 0 && B < 65536 && n > 0 && H > 0 && H < 65536 && W > 0 && mh > 0 && mw > 0, "instance_summary_rois: bad dims");
+    ML_REQUIRE(road_channel >= 0 && road_channel < seg_channels, "instance_summary_rois: road channel out of range");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *xmin = reinterpret_cast<int32_t *>(workspace);
+    int32_t *xmax = xmin + (size_t)B * H;
+    int32_t *last_row = xmax + (size_t)B * H;
+    float *unit = reinterpret_cast<float *>(last_row + B + ((B & 1) ? 1 : 0));
+    int32_t *thr = reinterpret_cast<int32_t *>(unit + (size_t)B * H);        // (the workspace size leaves 256 spare bytes)
+    ML_REQUIRE(hipMemsetAsync(last_row, 0xff, (size_t)B * sizeof(int32_t), s) == hipSuccess, "instance_summary_rois: memset failed");
+    hipLaunchKernelGGL(conf_threshold_kernel, dim3(1), dim3(256), 0, s, det, B * n, thr);
+    hipLaunchKernelGGL(road_row_extent_kernel, dim3(H, B), dim3(64), 0, s, seg, seg_channels, road_channel, H, W, xmin, xmax,
+                       last_row);
+    hipLaunchKernelGGL(road_unit_length_kernel, dim3(B), dim3(256), 0, s, xmin, xmax, last_row, H, default_road_size, unit);
+    const RoiSrc R = {det, roi_masks, thr, mh, mw};
+    void *part_ws = reinterpret_cast<char *>(workspace) + (ml_instance_summary_workspace_bytes(B, H) - SUMMARY_PART_BYTES) / 8 * 8;
+    launch_summary<true>(nullptr, R, seg, seg_channels, road_channel, unit, part_ws, B, n, H, W, ioi_threshold, out5, s);
+    ML_CHECK_LAUNCH("instance_summary_rois");
     return ML_OK;
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ml_nonzero_bbox_i32": (C.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),
     "ml_instance_summary_workspace_bytes": (_i64, [_i32, _i32]),
     "ml_instance_summary_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp] + [_i32] * 4 + [_f32, _f32, _vp, _vp]),
+    "ml_instance_summary_rois_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp] + [_i32] * 6 + [_f32, _f32, _vp, _vp]),
 }
 
 _lib = None

@@ -316,12 +316,24 @@ class SummaryOutput(Layer):
         super().__init__(**kwargs)
 
     def call(self, inputs, **kwargs):
+        """inputs[2] = CropAndPadMask's float32 [B,n,H,W] output (the reference's wiring), or -- `from_rois=True` --
+        that layer's own inputs' masks, int32 [B,n,mh,mw]: the canvases are then never materialised (3.4 GB at 8 x 100
+        instances of 1024^2; ml_instance_summary_rois_f32 recomputes the pasted values, bit-identical numbers)."""
         det_outs, seg_outs, crop_ins_outs = inputs[0], inputs[1], inputs[2]
         crack_det_outs, crack_seg_outs = CrackToInstance()(seg_outs, channel=2)              # :575
-        if bool((crack_det_outs[..., -1] > 0).all()):                                        # :577-583
-            det_outs = torch.cat([det_outs, crack_det_outs], dim=1)
-            crop_ins_outs = torch.cat([crop_ins_outs, crack_seg_outs], dim=1)
-        s = ops.instance_summary(seg_outs.contiguous(), crop_ins_outs.contiguous(), 1, self.default_road_size, 0.1)
+        with_crack = bool((crack_det_outs[..., -1] > 0).all())                               # :577-583
+        if kwargs.get("from_rois", False):
+            s = ops.instance_summary_rois(seg_outs.contiguous(), det_outs.contiguous(), crop_ins_outs.contiguous(), 1,
+                                          self.default_road_size, 0.1)
+            if with_crack:                          # the crack pseudo-instance is one full-size map per image: as before
+                s = torch.cat([s, ops.instance_summary(seg_outs.contiguous(), crack_seg_outs, 1, self.default_road_size,
+                                                       0.1)], dim=1)
+                det_outs = torch.cat([det_outs, crack_det_outs], dim=1)
+        else:
+            if with_crack:
+                det_outs = torch.cat([det_outs, crack_det_outs], dim=1)
+                crop_ins_outs = torch.cat([crop_ins_outs, crack_seg_outs], dim=1)
+            s = ops.instance_summary(seg_outs.contiguous(), crop_ins_outs.contiguous(), 1, self.default_road_size, 0.1)
         d = det_outs.to(torch.float32)
         cx, cy, w, h, classes, conf = [d[..., i] for i in range(6)]
         return torch.stack([classes, cx, cy, w, h, conf, s[..., 0], s[..., 1], s[..., 2], s[..., 3], s[..., 4]], dim=-1)

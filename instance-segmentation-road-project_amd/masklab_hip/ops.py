@@ -640,6 +640,25 @@ def semantic_smoothing(x, kernel_sizes, weights):
 
 
 # ----------------------------------------------------------------------------- serving post-processing
+def instance_summary_rois(seg, det_outs, ins_outs, road_channel=1, default_road_size=3.25, ioi_threshold=0.1):
+    """ml_instance_summary_rois_f32: crop_pad_mask + instance_summary without the [B,n,H,W] canvases (bit-identical).
+    seg int32 [B,H,W,C], det_outs int32 [B,n,6], ins_outs int32 [B,n,mh,mw] -> [B,n,5]."""
+    lib = _lib.load()
+    for t, name in ((seg, "seg"), (det_outs, "det_outs"), (ins_outs, "ins_outs")):
+        _require_dev(t, name)
+        if t.dtype != torch.int32:
+            raise RuntimeError("instance_summary_rois: int32 semantic map, detections and masks expected")
+    B, H, W, Cc = seg.shape
+    _, n, mh, mw = ins_outs.shape
+    out = torch.empty((B, n, 5), dtype=torch.float32, device=seg.device)
+    ws = workspace(int(lib.ml_instance_summary_workspace_bytes(B, H)), seg.device, "summary")
+    with _Prof("instance_summary_rois", 0, 4 * (ins_outs.numel() + 2 * seg.numel())):
+        _lib.check(lib.ml_instance_summary_rois_f32(_ptr(seg), Cc, int(road_channel), _ptr(det_outs), _ptr(ins_outs), _ptr(out),
+                                                    B, n, mh, mw, H, W, float(default_road_size), float(ioi_threshold),
+                                                    _ptr(ws), _stream()), "ml_instance_summary_rois_f32")
+    return out
+
+
 def crop_pad_mask(det_outs, ins_outs, height, width):
     """ml_crop_pad_mask_f32: det [B,n,6] int32, masks [B,n,mh,mw] int32 -> [B,n,H,W] float32."""
     lib = _lib.load()

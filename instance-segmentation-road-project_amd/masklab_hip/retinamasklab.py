@@ -489,8 +489,11 @@ class ServingModel(K.Layer):
             images = torch.as_tensor(np.asarray(images))
         images = images.to(self.deploy_model.model.device).contiguous()
         det_outs, ins_outs, seg_outs = self.deploy_model(images)                            # :27-29
-        crop_and_pad_masks = self.crop_and_pad([images, det_outs, ins_outs, seg_outs])      # :30
-        return self.summary([det_outs, seg_outs, crop_and_pad_masks])                       # :47-48
+        if kwargs.get("materialise_masks", False):                                          # the reference's literal wiring
+            crop_and_pad_masks = self.crop_and_pad([images, det_outs, ins_outs, seg_outs])  # :30
+            return self.summary([det_outs, seg_outs, crop_and_pad_masks])                   # :47-48
+        # CropAndPadMask folded into SummaryOutput: same numbers bit for bit, no [B,n,H,W] tensor
+        return self.summary([det_outs, seg_outs, ins_outs], from_rois=True)
 
     def predict(self, images, **kwargs):
         out = self.call(images, **kwargs)

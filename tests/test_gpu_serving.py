@@ -89,6 +89,34 @@ def test_summary_output(crack):
     assert want[..., 7].max() > 0 and 0 < want[..., 10].mean() < 1
 
 
+@pytest.mark.parametrize("seed,shape,crack", [(3, (2, 7, 90, 160), True), (11, (3, 9, 130, 200), False),
+                                              (5, (2, 5, 64, 300), True)])
+def test_summary_from_rois_is_bit_identical_to_the_materialised_path(seed, shape, crack):
+    """SummaryOutput(from_rois=True) (ml_instance_summary_rois_f32: CropAndPadMask folded into the summary kernels, only
+    the rows / column stripes a box covers are visited) against CropAndPadMask -> SummaryOutput on the [B,n,H,W] canvases:
+    every number equal bit for bit -- boxes overhanging the canvas, rows below the confidence cut, -1 padded rows, a
+    zero-sized box, boxes narrower than a 64-lane stripe and wider than 256 columns."""
+    from masklab_hip.layers import CropAndPadMask, SummaryOutput
+    B, n, H, W = shape
+    det, ins, seg = _scene(B=B, n=n, H=H, W=W, seed=seed, crack=crack)
+    det[0, 1, 2:4] = (W + 40, H + 20)                       # wider / taller than the canvas
+    det[0, 2, 0:4] = (-30, -30, 4, 4)                       # clipped to nothing
+    det[0, 3, 2:4] = (3, 2)                                 # a few pixels
+    images = dev(np.zeros((B, H, W, 3), np.uint8))
+    d, i, sg = dev(det), dev(ins), dev(seg)
+    layer = SummaryOutput(3.25)
+    want = host(layer([d, sg, CropAndPadMask()([images, d, i, sg])]))
+    got = host(layer([d, sg, i], from_rois=True))
+    assert got.shape == want.shape and want[..., 6].max() > 0
+    np.testing.assert_array_equal(got, want)
+    # all confidences <= 50: every row pasted (threshold -100)
+    det2 = det.copy()
+    det2[..., 5] = np.minimum(det2[..., 5], 40)
+    d2 = dev(det2)
+    np.testing.assert_array_equal(host(layer([d2, sg, i], from_rois=True)),
+                                  host(layer([d2, sg, CropAndPadMask()([images, d2, i, sg])])))
+
+
 def test_instance_size_without_any_road():
     from masklab_hip.layers import CalculateInstanceSize, IncludeMyRoad
     det, ins, seg = _scene(seed=5)
@@ -116,6 +144,7 @@ def test_serving_model_end_to_end():
     serving = R.construct_serving_network(cfg, R.construct_deploy_network(cfg, model))
     images = np.random.default_rng(1234).integers(0, 256, (2, 320, 640, 3), dtype=np.uint8)
     got = serving.predict(images)
+    np.testing.assert_array_equal(got, host(serving(dev(images), materialise_masks=True)))   # the reference's literal wiring
     want = O.serving_forward(cfg, w, images, literal_groups=False)
     assert got.shape == want.shape and got.shape[-1] == 11
     np.testing.assert_array_equal(got[..., 0], want[..., 0])                     # classes / padding rows
