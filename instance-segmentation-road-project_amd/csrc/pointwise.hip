@@ -138,17 +138,19 @@ __global__ void bilinear_ac_kernel(const float *__restrict__ in, const float *__
 }
 
 // ------------------------------------------------------------------ global mean over HW
-// grid (C4 / 64, B), block 256 = 4 row-groups x 64 channel-quads; fp64 accumulation.
+// grid (ceil(C4 / 16), B), block 256 = 16 row-groups x 16 channel-quads (256 contiguous bytes per row group); fp64
+// accumulation, the 16 partial sums of a channel added in a fixed order.  (The first layout -- 64 quads x 4 row groups
+// -- gave ASPP's pooling branch 64 blocks for 67 MB: 79 us.)
 __global__ void global_mean_kernel(const float *__restrict__ in, float *__restrict__ out, int HW, int C4) {
-    __shared__ double red[4][64][4];
-    const int q = threadIdx.x & 63;
-    const int g = threadIdx.x >> 6;
-    const int c4 = blockIdx.x * 64 + q;
+    __shared__ double red[16][16][4];
+    const int q = threadIdx.x & 15;
+    const int g = threadIdx.x >> 4;
+    const int c4 = blockIdx.x * 16 + q;
     const int b = blockIdx.y;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (c4 < C4) {
         const float *p = in + (long long)b * HW * C4 * 4 + c4 * 4;
-        for (int i = g; i < HW; i += 4) {
+        for (int i = g; i < HW; i += 16) {
             const f32x4 x = *reinterpret_cast<const f32x4 *>(p + (long long)i * C4 * 4);
             s0 += x[0]; s1 += x[1]; s2 += x[2]; s3 += x[3];
         }
@@ -158,8 +160,12 @@ __global__ void global_mean_kernel(const float *__restrict__ in, float *__restri
     if (g == 0 && c4 < C4) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[e] = (float)((red[0][q][e] + red[1][q][e] + red[2][q][e] + red[3][q][e]) / (double)HW);
+        for (int e = 0; e < 4; ++e) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][q][e];
+            o[e] = (float)(t / (double)HW);
+        }
         *reinterpret_cast<f32x4 *>(out + (long long)b * C4 * 4 + c4 * 4) = o;
     }
 }
@@ -262,7 +268,7 @@ extern "C" int ml_global_mean_f32(const float *in, float *out, int32_t B, int32_
     ML_REQUIRE(in && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "global_mean: bad arguments");
     ML_REQUIRE(ml_aligned16(in) && ml_aligned16(out), "global_mean: pointers must be 16-byte aligned");
     const int C4 = C / 4;
-    hipLaunchKernelGGL(global_mean_kernel, dim3((C4 + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, in, out, HW, C4);
+    hipLaunchKernelGGL(global_mean_kernel, dim3((C4 + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, in, out, HW, C4);
     ML_CHECK_LAUNCH("global_mean");
     return ML_OK;
 }
