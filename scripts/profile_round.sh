@@ -22,6 +22,7 @@ unset MASKLAB_SIDE_STREAM
 #      kernel's duration here includes the time it shares the chip with another
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $OUT/trace_c -o trace -- $BENCH > $OUT/bench_trace_concurrent.log 2>&1
 python3 scripts/rocpd_summary.py $(find $OUT/trace_c -name "*.db" | head -1) $OUT/kernel_trace_concurrent_summary.md > /dev/null
+python3 scripts/rocpd_timeline.py $(find $OUT/trace_c -name "*.db" | head -1) $OUT/timeline_concurrent.md > /dev/null
 echo "trace done"
 export MASKLAB_SIDE_STREAM=0
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE; do
