@@ -40,7 +40,7 @@ enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2 };
 
 #define ML_ABI_VERSION 3              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
-                                            conv GroupNorm-statistics epilogue, fp16 tensor storage   */
+                                            fp16 tensor storage                                       */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */

@@ -141,7 +141,7 @@ constexpr int NPC = 8;
 constexpr int RES_LEAD = 4;
 
 // One piece of the epilogue: sub-tile (qm, qn), rows 16 hs .. 16 hs + 15 of it.  r0 / r1: residual already loaded.
-template <class T, int Q, bool HAS_RES, int NB4>
+template <class T, int Q, bool HAS_RES, int NB4, bool CLAMP>
 __device__ __forceinline__ void finish_piece(const f32x16 (&acc)[2][2], const PipeState &S, char *scratch,
                                              __amdgpu_buffer_rsrc_t ro, const f32x4 (&bias)[2][NB4], f32x4 r0, f32x4 r1) {
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -169,10 +169,12 @@ __device__ __forceinline__ void finish_piece(const f32x16 (&acc)[2][2], const Pi
     }
     v0 += bias[qn][0];
     v1 += bias[qn][NB4 - 1];
+    if constexpr (CLAMP) {               // ML_ACT_NONE stores the sum as it is (NaN / Inf stay what they are)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        v0[c] = __builtin_amdgcn_fmed3f(v0[c], S.lo, S.hi);
-        v1[c] = __builtin_amdgcn_fmed3f(v1[c], S.lo, S.hi);
+        for (int c = 0; c < 4; ++c) {
+            v0[c] = __builtin_amdgcn_fmed3f(v0[c], S.lo, S.hi);
+            v1[c] = __builtin_amdgcn_fmed3f(v1[c], S.lo, S.hi);
+        }
     }
     if constexpr (F32) {
         buf_store16(v0, ro, S.t_voff[qn], S.rowoff[(qm * 2 + hs) * 2 + 0]);
@@ -193,7 +195,7 @@ __device__ __forceinline__ void finish_piece(const f32x16 (&acc)[2][2], const Pi
 //                         [p < NPC, residual] issue the residual load(s) of piece p (consumed LEAD pieces later).
 // Vector-memory issue order of a FIRST chunk, on which the hand-counted waits rely (sched_barrier pins it):
 //   8 staging loads, then per piece: stores(q) before loads(p).
-template <class T, bool FIRST, bool HAS_RES, int NB4>   // (the staging depth only shows in which buffer `wr` is)
+template <class T, bool FIRST, bool HAS_RES, int NB4, bool CLAMP>   // (the staging depth only shows in which buffer `wr` is)
 __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2][2], const PipeState &S, const char *rd,
                                            char *wr, char *scratch, __amdgpu_buffer_rsrc_t ra_nx,
                                            __amdgpu_buffer_rsrc_t rb_nx, int soff_nx, __amdgpu_buffer_rsrc_t ro_prev,
@@ -234,23 +236,11 @@ __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2]
             else cur[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, cur[mi][ni], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef PIPE_ABL_NODMA
-        if constexpr (false) {
-#else
         if constexpr (idx < 4) {
-#endif
             lds_dma16(ra_nx, wr + (32 * idx + 8 * S.wave_u) * ROWB, S.a_voff[idx], soff_nx);
-#ifdef PIPE_ABL_NODMA
-        } else if constexpr (false) {
-#else
         } else if constexpr (idx < 8) {
-#endif
             lds_dma16(rb_nx, wr + (BM + 32 * (idx - 4) + 8 * S.wave_u) * ROWB, S.b_voff[idx - 4], soff_nx);
-#ifdef PIPE_ABL_NOEPI
-        } else if constexpr (false) {
-#else
         } else if constexpr (FIRST) {
-#endif
             // pieces [pb, pe) ride after this MFMA: spread evenly over MFMAs 8 .. NSLOT-1
             constexpr int pb = ((idx - 8) * NREG) / (NSLOT - 8), pe = ((idx - 7) * NREG) / (NSLOT - 8);
             static_for<pb, pe>([&](auto pc) {
@@ -267,7 +257,7 @@ __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2]
                         if constexpr (F32) wait_loaded<younger>(ring[q % RES_LEAD][0], ring[q % RES_LEAD][1]);
                         else wait_loaded<younger>(ring[q % RES_LEAD][0]);
                     }
-                    finish_piece<T, q, HAS_RES, NB4>(oth, S, scratch, ro_prev, bias_prev, ring[q % RES_LEAD][0],
+                    finish_piece<T, q, HAS_RES, NB4, CLAMP>(oth, S, scratch, ro_prev, bias_prev, ring[q % RES_LEAD][0],
                                                      ring[q % RES_LEAD][F32 ? 1 : 0]);
                 }
                 if constexpr (HAS_RES && p < NPC) {
@@ -282,7 +272,7 @@ __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2]
     });
 }
 
-template <class T, bool HAS_RES, int NSTAGE>
+template <class T, bool HAS_RES, int NSTAGE, bool CLAMP>
 __global__ void __launch_bounds__(256, NSTAGE == 2 ? 2 : 1)
 conv1x1_pipe_kernel(const PipeArgs A) {
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -403,8 +393,8 @@ conv1x1_pipe_kernel(const PipeArgs A) {
             char *wr = lds + (buf == 0 ? NSTAGE - 1 : buf - 1) * BUFB;     // the buffer the previous chunk was read from
             const bool first = kc == 0;
             // (wave-uniform branch: two instantiations of the chunk per accumulator role)
-            if (first) pipe_chunk<T, true, HAS_RES, NB4>(acc, oth, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ro_prev, bias_prev, rr_prev);
-            else pipe_chunk<T, false, HAS_RES, NB4>(acc, oth, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ro_prev, bias_prev, rr_prev);
+            if (first) pipe_chunk<T, true, HAS_RES, NB4, CLAMP>(acc, oth, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ro_prev, bias_prev, rr_prev);
+            else pipe_chunk<T, false, HAS_RES, NB4, CLAMP>(acc, oth, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ro_prev, bias_prev, rr_prev);
             // advance the staging cursor
             ++kc_nx;
             if (kc_nx == nk) { kc_nx = 0; nx = advance(nx); }
@@ -444,7 +434,7 @@ conv1x1_pipe_kernel(const PipeArgs A) {
                     wait_loaded<0>(r0);
                 }
             }
-            finish_piece<T, q, HAS_RES, NB4>(acc, S, scratch, ro, bias_prev, r0, r1);
+            finish_piece<T, q, HAS_RES, NB4, CLAMP>(acc, S, scratch, ro, bias_prev, r0, r1);
         });
     };
     // the tile loop, unrolled by two so that the accumulator sets swap roles without register copies
@@ -454,9 +444,9 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     }
 }
 
-template <class T, bool HAS_RES, int NSTAGE>
+template <class T, bool HAS_RES, int NSTAGE, bool CLAMP>
 int launch_pipe(const PipeArgs &A, hipStream_t s) {
-    auto kern = conv1x1_pipe_kernel<T, HAS_RES, NSTAGE>;
+    auto kern = conv1x1_pipe_kernel<T, HAS_RES, NSTAGE, CLAMP>;
     static std::atomic<unsigned long long> ok{0};          // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), pipe_lds_bytes(NSTAGE) + 4 * PIPE_MAX_NBG * BN, ok,
                                        "conv1x1_pipe"))
@@ -511,7 +501,7 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     int best = -1;
     double best_eff = -1.0;
     for (int g = 0; (A.NB >> g) >= 1 && (A.NB % (1 << g)) == 0; ++g) {
-        if ((A.NB >> g) > PIPE_MAX_NBG) continue;
+        if ((A.NB >> g) > PIPE_MAX_NBG || (1 << g) > resident) continue;
         const long long units = (long long)A.panels << g;
         const long long rounds = (units + resident - 1) / resident;
         const double eff = (double)units / (double)(rounds * resident);
@@ -521,14 +511,19 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     A.gshift = best;
     A.NBG = A.NB >> A.gshift;
     A.units = A.panels << A.gshift;
-    A.grid = A.units < resident ? A.units : resident;
-    A.lo = d.act == ML_ACT_NONE ? -3.402823466e38f : 0.f;
+    // a block keeps ONE group's bias in LDS and advances by the grid size: the grid must be a multiple of the group count
+    A.grid = A.units < resident ? A.units : resident / (1 << A.gshift) * (1 << A.gshift);
+    const bool clamp = d.act != ML_ACT_NONE;
+    A.lo = 0.f;
     A.hi = d.act == ML_ACT_RELU6 ? 6.f : 3.402823466e38f;
     int rc;
-    if (d.math == ML_MATH_F16S)
-        rc = d.residual ? launch_pipe<_Float16, true, 2>(A, s) : launch_pipe<_Float16, false, 2>(A, s);
-    else
-        rc = d.residual ? launch_pipe<float, true, 2>(A, s) : launch_pipe<float, false, 2>(A, s);
+    if (d.math == ML_MATH_F16S) {
+        if (clamp) rc = d.residual ? launch_pipe<_Float16, true, 2, true>(A, s) : launch_pipe<_Float16, false, 2, true>(A, s);
+        else rc = d.residual ? launch_pipe<_Float16, true, 2, false>(A, s) : launch_pipe<_Float16, false, 2, false>(A, s);
+    } else {
+        if (clamp) rc = d.residual ? launch_pipe<float, true, 2, true>(A, s) : launch_pipe<float, false, 2, true>(A, s);
+        else rc = d.residual ? launch_pipe<float, true, 2, false>(A, s) : launch_pipe<float, false, 2, false>(A, s);
+    }
     if (rc != ML_OK) return rc;
     *eligible = 1;
     return ML_OK;

@@ -493,7 +493,9 @@ conv_mfma_kernel(const MultiArgs args) {
     if (fast_blk) {
         // fast path (every backbone / tower conv): dense or channel-sliced NHWC destination, float4 lanes,
         // ReLU / ReLU6 / none as a branch-free clamp.  Row pointers advance by a constant stride.
-        const float lo = (p.act == ML_ACT_NONE) ? -3.402823466e38f : 0.f;
+        // ML_ACT_NONE stores the sum as it is (no clamp: NaN / Inf stay what they are); block-uniform branch
+        const bool clampv = p.act != ML_ACT_NONE;
+        const float lo = 0.f;
         const float hi = (p.act == ML_ACT_RELU6) ? 6.f : 3.402823466e38f;
         const bool late_res = p.residual && !pre_res;
         const size_t cs = p.out_cstride;
@@ -520,8 +522,10 @@ conv_mfma_kernel(const MultiArgs args) {
                 const int m = m0 + r0 + i * ROWS_PER_PASS;
                 if (m < M) {
                     f32x4 v = tile_v[i];
+                    if (clampv) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                    }
                     const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                     *reinterpret_cast<f16x4 *>(oh + off + (size_t)i * ROWS_PER_PASS * cs) = hv;
                 }
@@ -533,8 +537,10 @@ conv_mfma_kernel(const MultiArgs args) {
             for (int i = 0; i < E_ROWS; ++i) {
                 f32x4 v = tile_v[i];
                 if (pre_res) v += res[i];
+                if (clampv) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                }
                 *reinterpret_cast<f32x4 *>(op + (size_t)i * step) = v;
             }
         } else {
@@ -545,8 +551,10 @@ conv_mfma_kernel(const MultiArgs args) {
                     f32x4 v = tile_v[i];
                     if (pre_res) v += res[i];
                     if (late_res) v += *reinterpret_cast<const f32x4 *>(p.residual + (size_t)m * p.res_cstride + p.res_coff + n);
+                    if (clampv) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+                    }
                     size_t o = off + (size_t)i * ROWS_PER_PASS * cs;
                     if (p.out_bstride) {
                         const int b = fast_div(m, P.div_howo);

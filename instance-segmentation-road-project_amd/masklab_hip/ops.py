@@ -14,6 +14,7 @@ from . import _lib
 from .packing import PackedConv, resolve_padding
 
 _ws_cache = {}
+_ws_retired = []     # superseded scratch buffers stay allocated: a captured hipGraph may still hold their addresses
 
 # When set to a list, every launcher appends {"kernel", "flops", "bytes", "start", "end"} with
 # torch.cuda.Event pairs recorded on the launch stream (bench.py's roofline leg).  `bytes` /
@@ -86,10 +87,13 @@ def _require_dev(t, name):
 
 def workspace(nbytes, device, tag="ws"):
     """Grow-only scratch buffer per (device, tag, stream); 256-byte aligned by the torch allocator.
-    Keyed by the launch stream too: work enqueued on two streams must not share scratch memory."""
+    Keyed by the launch stream too: work enqueued on two streams must not share scratch memory.  A buffer that is
+    outgrown is retired, never freed (graphs captured earlier replay with its address)."""
     key = (str(device), tag, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

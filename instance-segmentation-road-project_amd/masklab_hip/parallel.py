@@ -79,7 +79,10 @@ class AsyncDetectionGather:
         self.group = group
         self.stream = None
 
-    def launch(self, payload, cap):
+    def launch(self, payload, cap, snapshot=False):
+        """snapshot=True: `payload` is a buffer the NEXT forward rewrites in place (the outputs of a replayed hipGraph
+        are graph-owned: InferenceModel.outputs_graph_owned) -- the record is copied on the compute stream first, so
+        the collective never reads a buffer the following replay is already writing."""
         import torch.distributed as dist
         if dist.get_backend(self.group) == "gloo":          # CPU tests / one-GPU rehearsal: host-staged, synchronous
             out, _ = _gather0(payload, self.group)
@@ -87,6 +90,8 @@ class AsyncDetectionGather:
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
+        if snapshot:
+            payload = payload.clone()                       # 19 KB device copy, ordered before the next replay
         self.stream.wait_stream(main)                       # the forward that produced `payload`
         with torch.cuda.stream(self.stream):
             out, work = _gather0(payload, self.group, async_op=True)
@@ -99,6 +104,21 @@ class AsyncDetectionGather:
             work.wait()                                     # current stream waits for the collective (no host block)
             out.record_stream(torch.cuda.current_stream(self.device))
         return unpack_payload(out, cap)
+
+
+def check_merged(merged_rows, merged_counts, own_rows, own_counts, rank, world):
+    """The merged record must be Concatenate(axis=0) of the ranks' records (reference engine/parallel.py:92-107):
+    `world` x B_local images with this rank's rows at image offset rank * B_local.  -> None, or what is wrong."""
+    B = int(own_rows.shape[0])
+    if int(merged_rows.shape[0]) != B * world or int(merged_counts.shape[0]) != B * world:
+        return f"merged batch holds {int(merged_rows.shape[0])} images, expected {B} x {world}"
+    sl = slice(rank * B, (rank + 1) * B)
+    if not torch.equal(merged_counts[sl].to(own_counts.device, own_counts.dtype), own_counts):
+        return f"counts at offset {rank * B} are not rank {rank}'s"
+    mine, got = own_rows, merged_rows[sl].to(own_rows.device)
+    if not torch.equal(got.view(torch.int32), mine.contiguous().view(torch.int32)):      # bit patterns (-1 padding included)
+        return f"rows at offset {rank * B} are not rank {rank}'s"
+    return None
 
 
 def all_gather_outputs(tensors, group=None):

@@ -192,6 +192,7 @@ class InferenceModel(K.Layer):
 
     def load_weights(self, weights, device="cuda"):
         self.device = torch.device(device)
+        self._graphs = {}                    # captured graphs hold the addresses of the tensors being replaced
         for l in self.layers:
             l.load_weights(weights, self.device)
         return self
@@ -201,6 +202,7 @@ class InferenceModel(K.Layer):
         move the score distribution; everything else keeps its device copy)."""
         if self.detection_networks is None:
             raise RuntimeError("no detection networks")
+        self._graphs = {}
         for block in self.detection_networks[2].blocks:
             block[-1].load_weights(weights, self.device)
 
@@ -349,7 +351,11 @@ class InferenceModel(K.Layer):
 
     def _stage1_graphed(self, images):
         from . import ops
-        key = (tuple(images.shape), images.dtype, ops.CONV_MATH)
+        # kernel arguments are baked into a capture: everything they are computed from is part of the key
+        dp = self.detection_proposal
+        key = (tuple(images.shape), images.dtype, ops.CONV_MATH) + (
+            () if dp is None else (float(dp.min_confidence), float(dp.nms_iou_threshold), float(dp.post_iou_threshold),
+                                   int(dp.nms_max_output_size)))
         entry = self._graphs.get(key)
         if entry is None:
             if ops.PROFILE is not None:

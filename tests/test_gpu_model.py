@@ -323,3 +323,61 @@ def test_batch_32_at_1024_crosses_2gib_activations():
     for name, f, r in zip(names, full, ref):
         err = float(np.max(np.abs(f[31:32].cpu().numpy().astype(np.float64) - r)))
         assert err <= TOL, (name, err)
+
+
+@pytest.mark.parametrize("size", [512, 1024])
+def test_mobilenet_full_forward_at_config_size(size):
+    """BASELINE configs[0] (MobileNet, 1x512x512) and configs[1] (MobileNet + FPN + ASPP, 1x1024x1024) AT THEIR SIZE:
+    the full forward against the oracle on an order-stable fixture (class logits scaled so that scores pass 0.5 without
+    saturating, min_confidence in a score gap, oracle/fixtures.py): float outputs within 1e-3, kept (anchor, class)
+    rows and their ORDER exact (reference engine/backbone/base.py:253-258, engine/retinamasklab.py:420-495)."""
+    from oracle import fixtures as FX
+    cfg, model, w = _build("mobilenet", seed=0)
+    images = np.random.default_rng(1234).integers(0, 256, (1, size, size, 3), dtype=np.uint8)
+    c1, l1 = O.inference_forward(cfg, w, images, literal_groups=False, with_instance=False, with_semantic=False)
+    scale, _ = FX.choose_logit_scale(cfg, c1, l1, size, size)
+    assert scale is not None, "no order-stable logit scale on the grid"
+    w_fix = FX.scale_cls_logits(w, scale)
+    model.reload_class_outputs(w_fix)
+    want, internals = O.inference_forward(cfg, w_fix, images, literal_groups=False, return_internals=True,
+                                          min_confidence=lambda c: FX.gap_threshold(c)[0])
+    thr = internals["min_confidence"]
+    names = model.output_names
+    cls_ref, loc_ref = want[names.index("cls_pred")], want[names.index("loc_pred")]
+    kept_ref, stable = FX.order_stability(cfg, cls_ref, FX.boxes_from(cfg, loc_ref, size, size), thr, trials=8)
+    assert stable == 8 and len(kept_ref) >= 4, (stable, len(kept_ref))
+    cfg.detection.min_confidence = thr
+    model.detection_proposal.min_confidence = thr
+    got = model.predict(images, want_kept=True)
+    det = model.last_detections
+    n = int(det["counts"].cpu()[0])
+    np.testing.assert_array_equal(det["kept"].cpu().numpy()[0, :n], kept_ref[:, 1:])
+    _check(model, got, want)
+
+
+def test_batch_sharding_where_the_split_k_decision_differs():
+    """A shard and the full batch may take different split-K decisions (csrc/conv_mfma.hip choose_splits looks at the
+    launch's tile count: one 256x256 image gives the five tower levels 11 tiles -> K cut into slices; eight images give
+    88 tiles -> fewer slices).  The K sum is then cut at other places: results agree to fp32 rounding (2e-5), not bit
+    for bit, and the detections are the same rows."""
+    from masklab_hip import parallel
+    cfg, model, w = _build("mobilenet", seed=7, hot_cls=True)
+    images = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (8, 256, 256, 3), dtype=np.uint8))
+    outs = [o.clone() for o in model.call(images.cuda())]
+    full = {k: v.clone() for k, v in model.last_detections.items() if v is not None}
+    parts, shard_outs = [], []
+    for r in range(8):
+        o = model.call(parallel.shard_batch(images, r, 8).cuda())
+        parts.append({k: v.clone() for k, v in model.last_detections.items() if v is not None})
+        shard_outs.append([t.clone() for t in o])
+    torch.cuda.synchronize()
+    names = model.output_names
+    for n in ("cls_pred", "loc_pred", "seg_pred"):
+        i = names.index(n)
+        merged = torch.cat([so[i] for so in shard_outs])
+        assert float((merged - outs[i]).abs().max()) <= 2e-5, n
+    counts = torch.cat([p["counts"] for p in parts])
+    assert torch.equal(counts, full["counts"])
+    prop = torch.cat([p["proposed"] for p in parts])
+    assert torch.equal(prop[..., 4], full["proposed"][..., 4])                       # same classes, same order
+    assert float((prop - full["proposed"]).abs().max()) <= 1e-3

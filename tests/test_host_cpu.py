@@ -351,8 +351,17 @@ def test_keras_h5_converter_maps_reference_auto_names_by_creation_order(flags, u
     # without the creation-order mapping nothing under the towers is found (what round 1's converter did)
     _, rep0 = conv.match_to_model(got, specs)
     assert len(rep0["missing"]) > 100
-    matched, rep = conv.match_to_model(conv.rename_keras_auto_names(got, specs), specs)
+    table = []
+    matched, rep = conv.match_to_model(conv.rename_keras_auto_names(got, specs, table), specs)
     assert rep["missing"] == [] and rep["shape_mismatch"] == [] and rep["unexpected"] == []
+    # the applied creation-order pairing is reported row by row (what a user with a real .h5 audits)
+    assert len(table) == len({r[4] for r in table}) and all(r[3].split("/")[-1].startswith(r[1]) for r in table)
+    laterals = [r for r in table if r[0] == "feature_pyramid"]
+    assert [r[4] for r in sorted(laterals, key=lambda r: r[2])] == [f"feature_pyramid/C{k}_lateral" for k in (5, 4, 3)]
+    import io
+    buf = io.StringIO()
+    conv.print_order_table(table, file=buf)
+    assert buf.getvalue().count("  ->  ") == len(table)
     for k in w:
         np.testing.assert_array_equal(matched[k], w[k], err_msg=k)
     # a checkpoint of a different head configuration is refused, not mis-assigned

@@ -41,6 +41,10 @@ def _worker(rank, world, port, q):
         assert torch.equal(vp, allp) and torch.equal(vc, allc) and vc.dtype == torch.int32
         p3, c3 = parallel.all_gather_detections(prop, counts, payload=payload)
         assert torch.equal(p3, allp) and torch.equal(c3, allc)
+        # bench.py's post-run assertion: B x world images, this rank's rows at offset rank (else a non-zero exit)
+        assert parallel.check_merged(vp, vc, prop, counts, rank, world) is None
+        assert "offset" in parallel.check_merged(vp, vc, prop, counts, 1 - rank, world)        # someone else's slot
+        assert "expected" in parallel.check_merged(vp[:2], vc[:2], prop, counts, rank, world)  # unmerged record
         seg = torch.full((2, 3, 3, 3), float(rank))
         (allseg,) = parallel.all_gather_outputs([seg])
         q.put((rank, allp.numpy(), allc.numpy(), allseg.numpy()))
@@ -85,3 +89,17 @@ def test_single_process_passthrough_and_shard_errors():
         parallel.shard_batch(torch.zeros(5, 2, 2, 3), 0, 2)
     with pytest.raises(ValueError):
         parallel.shard_batch(torch.zeros(66, 1, 1, 3), 0, 2)         # 33 per GPU > MoldBatch limit
+
+
+def test_bench_sets_dmabuf_ipc_in_every_rank():
+    """bench.py must export HSA_ENABLE_IPC_MODE_LEGACY=0 in the rank process itself (the driver launches the ranks with
+    torch.distributed.run, not through bench.py's own spawner): main() sets it before anything imports torch.cuda."""
+    import ast
+    import pathlib
+    src = pathlib.Path(__file__).resolve().parents[1].joinpath("bench.py").read_text()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    first_calls = [ast.unparse(n) for n in main.body[:4]]
+    assert any("HSA_ENABLE_IPC_MODE_LEGACY" in c and "setdefault" in c for c in first_calls), first_calls
+    spawn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "spawn_ranks")
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in ast.unparse(spawn)        # one place only: no launch-dependent difference

@@ -113,10 +113,12 @@ def _our_sublayers(specs):
     return {sc: {cls: [p for _, p in sorted(lst)] for cls, lst in d.items()} for sc, d in out.items()}
 
 
-def rename_keras_auto_names(weights, specs):
+def rename_keras_auto_names(weights, specs, table=None):
     """Rewrite the keys of a reference-named weight dict (`<...>/<scope>[_k]/<auto name>/.../<weight>`) to this
     package's names.  Keys that are not under an auto-named sub-layer are returned unchanged.  Raises ValueError
-    when a scope holds a different number of auto-named sub-layers of some class than the model declares."""
+    when a scope holds a different number of auto-named sub-layers of some class than the model declares.
+    `table` (a list) receives one (scope, keras class, N, checkpoint prefix, model prefix) row per matched sub-layer:
+    the creation-order pairing that was applied, for a user to audit against their checkpoint."""
     ours = _our_sublayers(specs)
     found = {}                                      # (scope, class) -> {N: file prefix up to the sub-layer}
     located = []                                    # (key, scope, class, N, remainder parts)
@@ -140,6 +142,8 @@ def rename_keras_auto_names(weights, specs):
                              f"use_squeeze_excite / use_separable_conv)?")
         for r, n in enumerate(sorted(by_n)):
             rank[(sc, cls, n)] = want[r]
+            if table is not None:
+                table.append((sc, cls, n, by_n[n], want[r]))
     out = dict(weights)
     dense_seen = {}
     for key, sc, cls, n, rest in located:
@@ -169,6 +173,17 @@ def rename_keras_auto_names(weights, specs):
         del out[key]
         out[f"{target}/dense{which}/" + "/".join(rest[1:])] = weights[key]
     return out
+
+
+def print_order_table(table, file=None):
+    """The pairing rename_keras_auto_names applied, one line per auto-named sub-layer: Keras numbers `conv2d_N`,
+    `group_normalization_N`, ... from one session-wide counter per class, so only the ORDER of the N's inside a
+    custom layer is meaningful (engine/layers/detection.py:39-43,109-130,179-202, instance.py:177-201,
+    semantic.py:205-219); check a few rows against `model.summary()` / the layer's sub-layers of the checkpoint."""
+    file = file or sys.stderr
+    print("creation-order table (checkpoint sub-layer -> this package's name):", file=file)
+    for sc, cls, n, src, dst in sorted(table, key=lambda r: (r[0], r[1], r[2])):
+        print(f"  {sc:24s} {cls:24s} N={n:<5d} {src}  ->  {dst}", file=file)
 
 
 def match_to_model(weights, specs):
@@ -222,6 +237,7 @@ def main(argv=None):
     ap.add_argument("npz_path")
     ap.add_argument("--backbone", default="resnext50")
     ap.add_argument("--allow-missing", action="store_true")
+    ap.add_argument("--quiet", action="store_true", help="do not print the creation-order table that was applied")
     args = ap.parse_args(argv)
     try:
         import h5py
@@ -231,7 +247,10 @@ def main(argv=None):
     with h5py.File(args.h5_path, "r") as f:
         weights = collect_h5_weights(f)
     specs = model_specs(args.backbone)
-    matched, report = match_to_model(rename_keras_auto_names(weights, specs), specs)
+    table = []
+    matched, report = match_to_model(rename_keras_auto_names(weights, specs, table), specs)
+    if not args.quiet:
+        print_order_table(table)
     for k in ("missing", "shape_mismatch"):
         for item in report[k]:
             print(f"{k}: {item}", file=sys.stderr)
