@@ -38,9 +38,12 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2 };
 
-#define ML_ABI_VERSION 3              /* 2: ml_conv2d_desc gained `math` / `reserved0`
+#define ML_ABI_VERSION 4              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
-                                            fp16 tensor storage                                       */
+                                            fp16 tensor storage
+                                         4: fp16 storage in the heads: ML_MATH_F16S on the generic conv,
+                                            ml_gn_desc.dtype, the *_f16 entry points of GroupNorm, resize,
+                                            depthwise conv, global mean, RoI crop and the mask-head tail  */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -80,13 +83,18 @@ typedef struct ml_conv2d_desc {
                                ML_MATH_F16: operands rounded to fp16 on their way into LDS,
                                v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5);
                                tensors in HBM stay fp32 either way;
-                               ML_MATH_F16S: fp16 STORAGE -- in / wgt / residual / out point to IEEE half
-                               data (element counts and strides unchanged), fp16 MFMA, fp32 accumulation,
+                               ML_MATH_F16S: fp16 STORAGE -- in / wgt / residual point to IEEE half data
+                               (element counts and strides unchanged; span_pad = span rounded up to 64,
+                               span / in_cstride / in_coff multiples of 8), fp16 MFMA, fp32 accumulation,
                                bias (fp32) + residual + activation in fp32, one rounding at the store.
-                               1x1 stride-1 problems with cout % 128 == 0 and span % 64 == 0 only
-                               (the ResNeXt bottleneck convs: conv1x1_pipe.hip)                 */
-    int32_t out_f16;        /* ML_MATH_F16 only: 1 = `out` is IEEE half (the stem feeding an fp16-storage
-                               body); else 0                                                   */
+                               1x1 stride-1 problems with cout % 128 == 0 and span % 64 == 0 run on the
+                               persistent kernel (conv1x1_pipe.hip: half output, optional half residual);
+                               every other shape on the generic kernel (no residual; output half or fp32
+                               by `out_f16`)                                                     */
+    int32_t out_f16;        /* 1 = `out` is IEEE half: ML_MATH_F16 (the stem feeding an fp16-storage body)
+                               and ML_MATH_F16S on the generic kernel (0 there = fp32 `out`: the prediction
+                               tensors); dense fast epilogue only (no residual / shuffle2x2 / out_bstride /
+                               sigmoid, cout % 4 == 0).  The persistent kernel always writes half.      */
     int64_t out_bstride;    /* floats between images in `out`; 0 = Ho*Wo*out_cstride (dense).
                                Lets a level's head write straight into the concatenated
                                [B, A, classes] prediction (detection.py:210-212 Reshape+Concatenate) */
@@ -133,8 +141,23 @@ int ml_maxpool3x3s2_f16(const void *in, void *out, int32_t B, int32_t H, int32_t
 /* out[b,oy,ox,:] = in[b,2oy,2ox,:] on fp16 [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C]: the sampling of a 1x1
  * stride-2 conv (the strided shortcuts, ResNext.py:199-203), which then runs as a stride-1 ML_MATH_F16S conv. */
 int ml_subsample2_f16(const void *in, void *out, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
-/* n halves -> n floats (the backbone taps handed to the fp32 heads), n % 8 == 0 */
+/* n halves -> n floats / n floats -> n halves (tensors crossing between an fp16-storage and an fp32 part), n % 8 == 0 */
 int ml_cast_f16_to_f32(const void *in, float *out, int64_t n, void *stream);
+int ml_cast_f32_to_f16(const float *in, void *out, int64_t n, void *stream);
+/* The heads on IEEE-half tensors (fp16 storage beyond the backbone body, BASELINE configs[4]): the arithmetic of
+ * ml_resize_bilinear_ac_f32 (engine/layers/misc.py:306 + the FPN Add detection.py:58-60 / concat-slice store
+ * semantic.py:154,227), ml_dwconv3x3_f32 (semantic.py:63-64) and ml_global_mean_f32 (semantic.py:149) on half
+ * in / add / out (weights and bias fp32), computed in fp32 with one rounding at the store; channel counts, strides
+ * and offsets multiples of 8.                                                                                    */
+int ml_resize_bilinear_ac_f16(const void *in, const void *add, void *out,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                              int32_t Ho, int32_t Wo, int32_t add_cstride, int32_t add_coff,
+                              int32_t out_cstride, int32_t out_coff, void *stream);
+int ml_dwconv3x3_f16(const void *in, const float *wgt, const float *bias, void *out,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                     int32_t out_cstride, int32_t out_coff, int32_t Ho, int32_t Wo,
+                     int32_t stride, int32_t dil, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
+int ml_global_mean_f16(const void *in, void *out, int32_t B, int32_t HW, int32_t C, void *stream);
 
 /* ---------------------------------------------------------------- fused mask-head tail
  * Conv2DTranspose(C_mid, (2,2), (2,2)) + bias + act_mid followed by Conv2D(ncls, (1,1)) + bias + act_out in one
@@ -157,6 +180,10 @@ typedef struct ml_deconv_out_problem {
     int64_t out_image_stride, out_base;
 } ml_deconv_out_problem;
 int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid, int32_t ncls,
+                            int32_t cp, int32_t act_mid, int32_t act_out, void *stream);
+/* The same with `x` and `wd` in IEEE half (the fp16-storage mask head; K % 64 == 0): the transposed conv runs on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation; bias, the 1x1 conv (fp32 table), sigmoid and `out` stay fp32. */
+int ml_deconv2x2_out1x1_f16(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid, int32_t ncls,
                             int32_t cp, int32_t act_mid, int32_t act_out, void *stream);
 
 /* ---------------------------------------------------------------- depthwise / pooling
@@ -192,6 +219,11 @@ int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const f
                            int32_t N, int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu,
                            int32_t out_cstride, int32_t out_coff, /* y view: channels of the buffer / first channel; (C,0) = dense */
                            void *workspace, void *stream);
+/* The same on IEEE-half tensors (x, y half; gamma / beta float): the heads of the fp16 path (BASELINE configs[4]).
+ * Statistics are fp64 sums of the stored values, the normalisation runs in fp32, one rounding at the store. */
+int ml_groupnorm_chunk_f16(const void *x, void *y, const float *gamma, const float *beta,
+                           int32_t N, int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu,
+                           int32_t out_cstride, int32_t out_coff, void *workspace, void *stream);
 
 /* Several independent GroupNormalizations in one launch pair (the five pyramid levels of a tower depth,
  * detection.py:124,194; the three RoI levels of the mask head, instance.py:192): the few-thousand-float problems of
@@ -206,7 +238,8 @@ typedef struct ml_gn_desc {
     int32_t N, C, G, relu;
     int32_t out_cstride, out_coff; /* y view, as in ml_groupnorm_chunk_f32          */
     float eps;
-    int32_t reserved;
+    int32_t dtype;                 /* 0: x / y are float; 1: x / y point to IEEE half (fp16-storage heads;
+                                      HWC/G and C multiples of 8); gamma / beta are float either way */
 } ml_gn_desc;
 #define ML_GN_MAX_PROBLEMS 8
 int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes, void *stream);
@@ -267,6 +300,12 @@ int ml_mask_distribute_i32(const float *rows, int32_t row_stride, int32_t has_k,
 int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int32_t row_stride, int32_t row_off,
                            const int32_t *level_slots,
                            const int32_t *level_counts, float *roi_fmaps, float *roi_boxes,
+                           int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
+                           int32_t level, int32_t n_l, int32_t ch, int32_t cw,
+                           float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);
+/* The same with fmap / roi_fmaps in IEEE half (C % 8 == 0): the mask head of the fp16 path; boxes and rows stay fp32. */
+int ml_roi_crop_resize_f16(const void *fmap, const float *rows, int32_t row_stride, int32_t row_off,
+                           const int32_t *level_slots, const int32_t *level_counts, void *roi_fmaps, float *roi_boxes,
                            int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
                            int32_t level, int32_t n_l, int32_t ch, int32_t cw,
                            float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);

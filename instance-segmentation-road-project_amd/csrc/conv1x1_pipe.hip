@@ -466,6 +466,8 @@ int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d) {
                           d.cpp_shift == 30 && d.group_cin_step == 0 && d.shuffle2x2 == 0 && d.out_bstride == 0 &&
                           (d.math == ML_MATH_F32 || f16s) && d.Ho == d.H && d.Wo == d.W;
     if (!shape_ok) return 0;
+    if (f16s && !d.out_f16) return 0;                     // this kernel stores the tensor type it reads (fp32 predictions: generic kernel)
+    if (!f16s && d.out_f16) return 0;
     if (d.span % kc != 0 || d.cout % 128 != 0 || d.n_pad != d.cout) return 0;
     if (!f16s && d.span != d.span_pad) return 0;
     if (d.act == ML_ACT_SIGMOID) return 0;

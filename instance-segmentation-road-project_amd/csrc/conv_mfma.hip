@@ -117,7 +117,12 @@ __device__ __forceinline__ void store_out4(const ml_conv2d_desc &p, int HoWo, in
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], p.act);
-        *reinterpret_cast<f32x4 *>(p.out + base) = r;
+        if (p.out_f16) {
+            const f16x4 hv = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+            *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + base) = hv;
+        } else {
+            *reinterpret_cast<f32x4 *>(p.out + base) = r;
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -125,7 +130,9 @@ __device__ __forceinline__ void store_out4(const ml_conv2d_desc &p, int HoWo, in
             float x = v[e];
             if (p.bias) x += p.bias[o + e];
             if (p.residual) x += p.residual[(size_t)m * p.res_cstride + p.res_coff + n + e];
-            p.out[base + e] = ml_apply_act(x, p.act);
+            x = ml_apply_act(x, p.act);
+            if (p.out_f16) reinterpret_cast<_Float16 *>(p.out)[base + e] = (_Float16)x;
+            else p.out[base + e] = x;
         }
     }
 }
@@ -143,9 +150,18 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
 // rounded to fp16 (RNE) on their way into LDS, and the contraction runs on v_mfma_f32_32x32x16_f16 with
 // fp32 accumulation -- 2 instructions of 32 cycles per 32-deep chunk and tile pair instead of 16 of 64.
 // Everything outside the K loop (addressing, prefetch pieces, epilogue, split-K) is shared.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool F16>
+// MATH = ML_MATH_F16S: fp16 STORAGE (the heads of the fp16 path): activations and weights are IEEE half in HBM.  A K
+// chunk is still 128 bytes per row (64 halves), so staging (LDS-direct loads, XOR swizzle), fragment addressing and the
+// prefetch pieces are the f32 code with the element size changed; a chunk is 4 k-steps of v_mfma_f32_32x32x16_f16
+// (one ds_read_b128 = the 8 halves a lane feeds).  Accumulation, bias and activation are fp32; the output is half
+// (`out_f16`, one rounding at the store) or fp32 (the prediction tensors detect.hip reads).
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const MultiArgs args) {
+    constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
+    constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
+    constexpr int ES = HS ? 2 : 4;                 // bytes per tensor element
+    constexpr int KC = HS ? 64 : 32;               // elements per K chunk
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
@@ -184,7 +200,8 @@ conv_mfma_kernel(const MultiArgs args) {
     const int ld_row = tid >> 3;
     // f32 math: lane (row, slot) of a staging load FETCHES k-group slot ^ ((row >> 1) & 7), so the linear LDS
     // image the load writes is the swizzled one (row + 32 i has the same swizzle key)
-    const int ld_c = F16 ? (tid & 7) * 4 : (((tid & 7) ^ ((ld_row >> 1) & 7)) * 4);
+    // (in ELEMENTS: a 16-byte k-group is 4 floats or 8 halves)
+    const int ld_c = F16 ? (tid & 7) * 4 : (((tid & 7) ^ ((ld_row >> 1) & 7)) * (16 / ES));
 
     // ---- per-thread pixel coordinates of the A rows it stages.  a_voff[i] = byte offset of the
     // row's tap-(0,0) pixel, channel gofs + ld_c: per chunk only a wave-uniform (tap, channel) offset
@@ -196,7 +213,7 @@ conv_mfma_kernel(const MultiArgs args) {
     // 1x1 / stride-1 / unpadded convs (most of the backbone): every tap of a valid row is inside the image,
     // so the per-row compares vanish and invalid tail rows rely on their out-of-range base offset.
     const bool nohalo = (p.KH == 1) && (p.KW == 1) && (p.pad_t == 0) && (p.pad_l == 0) && (p.stride == 1) &&
-                        (p.cpp_shift == 30) && (p.span % 32 == 0);
+                        (p.cpp_shift == 30) && (p.span % KC == 0);
     // Setup and epilogue run beside the co-resident block's MFMA stream, which leaves them about one VALU
     // issue slot per 64-cycle MFMA (measured: 2 400 cycles for the ~140 instructions below, 9 100 for the
     // ~150 of the store loop) -- so what counts here is the instruction COUNT, not the latency.
@@ -207,7 +224,7 @@ conv_mfma_kernel(const MultiArgs args) {
             // output pixel m reads input pixel m: no (b, y, x) decomposition, no divisions
             a_iy0[i] = 0;
             a_ix0[i] = 0;
-            a_voff[i] = m < M ? (int)(((long long)m * (long long)p.in_cstride + gofs + ld_c) * 4) : (int)0x80000000;
+            a_voff[i] = m < M ? (int)(((long long)m * (long long)p.in_cstride + gofs + ld_c) * ES) : (int)0x80000000;
         } else if (m < M) {
             const int b = fast_div(m, P.div_howo);
             const int r = m - b * HoWo;
@@ -216,7 +233,7 @@ conv_mfma_kernel(const MultiArgs args) {
             a_iy0[i] = oy * p.stride - p.pad_t;
             a_ix0[i] = ox * p.stride - p.pad_l;
             a_voff[i] = (int)((((long long)b * p.H * p.W + (long long)a_iy0[i] * p.W + a_ix0[i]) * (long long)p.in_cstride +
-                               gofs + ld_c) * 4);
+                               gofs + ld_c) * ES);
         } else {
             a_iy0[i] = -(1 << 28);
             a_ix0[i] = 0;
@@ -265,9 +282,9 @@ conv_mfma_kernel(const MultiArgs args) {
     // running wave-uniform state of the NEXT chunk: tap offsets (dy, dx), element offset toff of
     // (tap, channel chunk) relative to a row's tap-(0,0) pixel -- updated with scalar adds only
     int dy = kh * pdil, dx = kw * pdil;
-    int toff = (int)(((long long)dy * pW + dx) * pcs) + cc * 32;
-    const int step_kw = (int)(pdil * pcs) - (ncpt - 1) * 32;                       // next tap in the row
-    const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs) - (ncpt - 1) * 32;
+    int toff = (int)(((long long)dy * pW + dx) * pcs) + cc * KC;
+    const int step_kw = (int)(pdil * pcs) - (ncpt - 1) * KC;                       // next tap in the row
+    const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs) - (ncpt - 1) * KC;
     // The next chunk's prefetch is split into PIECES (one A row or one B row each: ~12 VALU + 1 global
     // load) that the K loop pins between individual MFMAs with sched_barrier(0): a wave that issues MFMAs
     // back to back owns its SIMD's issue port, so non-MFMA work only overlaps matrix work when it sits in
@@ -277,7 +294,7 @@ conv_mfma_kernel(const MultiArgs args) {
     int dst_buf = 0;                                      // staging buffer the pieces fill
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto piece_begin = [&]() {
-        const int c = cc * 32 + ld_c;
+        const int c = cc * KC + ld_c;
         nx_px = c >> pshift;                     // 0 unless a tap spans pixels (NHWC4 stems)
         nx_cok = c < pspan;
     };
@@ -291,9 +308,9 @@ conv_mfma_kernel(const MultiArgs args) {
     __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, wgt_bytes, 0x00020000);
     int b_voff[B_LD];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * 4;
+    for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * ES;
     auto piece_a = [&](int i) {
-        int vo = a_voff[i] + toff * 4;
+        int vo = a_voff[i] + toff * ES;
         if (!nohalo) {                            // wave-uniform
             const int iy = a_iy0[i] + dy;
             const int ix = a_ix0[i] + dx;
@@ -317,7 +334,7 @@ conv_mfma_kernel(const MultiArgs args) {
     auto piece_end = [&]() {                     // advance (kh, kw, cc) and the running offsets with selects
         const bool wrap_c = (cc + 1 == ncpt);
         const bool wrap_w = wrap_c && (kw + 1 == pKW);
-        toff += wrap_w ? step_kh : (wrap_c ? step_kw : 32);
+        toff += wrap_w ? step_kh : (wrap_c ? step_kw : KC);
         dx = wrap_w ? 0 : (wrap_c ? dx + pdil : dx);
         dy = wrap_w ? dy + pdil : dy;
         kw = wrap_w ? 0 : (wrap_c ? kw + 1 : kw);
@@ -423,6 +440,40 @@ conv_mfma_kernel(const MultiArgs args) {
             }
 #pragma unroll
             for (int q = 0; q < NPIECE; ++q)                 // what did not fit between the MFMAs
+                if (q >= placed) {
+                    if (q < A_LD) piece_a(q);
+                    else if (q < A_LD + B_LD) piece_b(q - A_LD, kc_next);
+                    else piece_end();
+                }
+        } else if constexpr (HS) {
+            // lane (r, h) feeds A[row r][k = 16 ks + 8 h + j], j = 0..7: the 16-byte k-group 2 ks + h of its row
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    a[mi] = *reinterpret_cast<const f32x4 *>(base + a_off + mi * 32 * LDS_LD + (((ks * 2 + h) ^ swz) * 4));
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    b[ni] = *reinterpret_cast<const f32x4 *>(base + b_off + ni * 32 * LDS_LD + (((ks * 2 + h) ^ swz) * 4));
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mi]),
+                                                                             __builtin_bit_cast(f16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+                        if (placed < NPIECE) {               // one prefetch piece per MFMA
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (placed < A_LD) piece_a(placed);
+                            else if (placed < A_LD + B_LD) piece_b(placed - A_LD, kc_next);
+                            else piece_end();
+                            ++placed;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)                 // what did not fit between the MFMAs (narrow tiles)
                 if (q >= placed) {
                     if (q < A_LD) piece_a(q);
                     else if (q < A_LD + B_LD) piece_b(q - A_LD, kc_next);
@@ -617,22 +668,28 @@ int pick_tile(int cout, int tile) {
     return 1;
 }
 
-int validate(const ml_conv2d_desc &d) {
+// generic = the checks of the implicit-GEMM kernel in this file (the persistent 1x1 kernel has its own eligibility test)
+int validate(const ml_conv2d_desc &d, bool generic = true) {
     ML_REQUIRE(d.in && d.wgt && d.out, "conv2d: null tensor pointer");
     ML_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0, "conv2d: bad spatial dims");
     ML_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0, "conv2d: bad kernel geometry");
-    ML_REQUIRE(d.span > 0 && d.span % 4 == 0, "conv2d: span %d must be a positive multiple of 4", d.span);
-    ML_REQUIRE(d.span_pad == (d.span + 31) / 32 * 32, "conv2d: span_pad %d != ceil32(span %d)", d.span_pad, d.span);
-    ML_REQUIRE(d.in_cstride % 4 == 0 && d.in_coff % 4 == 0 && d.group_cin_step % 4 == 0,
-               "conv2d: input channel stride/offset must be multiples of 4 (16-byte loads)");
+    const bool hs = d.math == ML_MATH_F16S;
+    const int es = hs ? 2 : 4, q16 = 16 / es, kc = hs ? 64 : 32;          // element bytes, elements per 16 bytes / per chunk
+    ML_REQUIRE(d.span > 0 && d.span % q16 == 0, "conv2d: span %d must be a positive multiple of %d", d.span, q16);
+    ML_REQUIRE(d.span_pad == (d.span + kc - 1) / kc * kc, "conv2d: span_pad %d != span %d rounded up to %d", d.span_pad, d.span, kc);
+    ML_REQUIRE(d.in_cstride % q16 == 0 && d.in_coff % q16 == 0 && d.group_cin_step % q16 == 0,
+               "conv2d: input channel stride/offset must be multiples of %d (16-byte loads)", q16);
+    if (hs)
+        ML_REQUIRE(d.cpp_shift == 30 && d.group_cin_step == 0,
+                   "conv2d: fp16 storage takes no image (row-span) input and no grouped windows");
     ML_REQUIRE(ml_aligned16(d.in) && ml_aligned16(d.wgt), "conv2d: in/wgt must be 16-byte aligned");
     ML_REQUIRE(d.cpp_shift >= 0 && d.cpp_shift <= 30, "conv2d: bad cpp_shift");
     ML_REQUIRE(d.cout > 0 && d.out_cstride > 0 && d.out_coff >= 0 && d.out_bstride >= 0, "conv2d: bad output channels");
     ML_REQUIRE((long long)d.B * d.H * d.W < (1ll << 31) / 2, "conv2d: too many input pixels for int32 indexing");
     ML_REQUIRE((long long)d.B * d.Ho * d.Wo < (1ll << 31) - 256, "conv2d: too many output pixels");
-    ML_REQUIRE((long long)d.H * d.W * d.in_cstride * 4 < (1ll << 31),
+    ML_REQUIRE((long long)d.H * d.W * d.in_cstride * es < (1ll << 31),
                "conv2d: ONE image of the input must be < 2 GiB (32-bit buffer offsets inside an image group)");
-    ML_REQUIRE((long long)d.n_pad * d.KH * d.KW * d.span_pad * 4 < (1ll << 31), "conv2d: weight tensor must be < 2 GiB");
+    ML_REQUIRE((long long)d.n_pad * d.KH * d.KW * d.span_pad * es < (1ll << 31), "conv2d: weight tensor must be < 2 GiB");
     if (d.shuffle2x2) {
         ML_REQUIRE(d.cout % 4 == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Ho == d.H && d.Wo == d.W,
                    "conv2d: shuffle2x2 needs a 1x1 stride-1 problem with cout = 4*Cout");
@@ -643,8 +700,8 @@ int validate(const ml_conv2d_desc &d) {
     }
     if (d.residual) ML_REQUIRE(d.res_coff + d.cout <= d.res_cstride, "conv2d: residual slice exceeds buffer");
     ML_REQUIRE(d.out_f16 == 0 || d.out_f16 == 1, "conv2d: out_f16 must be 0 or 1");
-    if (d.out_f16)
-        ML_REQUIRE(d.math == ML_MATH_F16 && !d.residual && !d.shuffle2x2 && d.out_bstride == 0 && d.act != ML_ACT_SIGMOID &&
+    if (d.out_f16 && generic)
+        ML_REQUIRE((d.math == ML_MATH_F16 || hs) && !d.residual && !d.shuffle2x2 && d.out_bstride == 0 && d.act != ML_ACT_SIGMOID &&
                        d.cout % 4 == 0 && d.out_cstride % 4 == 0 && d.out_coff % 4 == 0 && (((uintptr_t)d.out) & 7) == 0,
                    "conv2d: out_f16 needs the fp16 MFMA mode, the dense fast epilogue (no residual / shuffle / batch "
                    "stride / sigmoid) and 4-channel alignment");
@@ -683,16 +740,18 @@ int choose_splits(long long tiles, int chunks) {
 
 // split_tiles >= 0: the tile count the split-K decision is taken on (see narrow_tile_for_small_launch), else this
 // launch's own
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool F16>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s,
                  long long split_tiles = -1) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
+    constexpr bool F16 = MATH == ML_MATH_F16;
+    constexpr int ES = MATH == ML_MATH_F16S ? 2 : 4, KC = MATH == ML_MATH_F16S ? 64 : 32;
     constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : 2 * (BM + BN) * LDS_LD * 4;
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
     constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     constexpr int LDS_BYTES = LDS_BYTES0;
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, F16>;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH>;
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "conv2d")) return rc;
     MultiArgs args;
@@ -714,15 +773,15 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.M = (int)M;
         P.MB = (int)((M + BM - 1) / BM);
         P.NB = d.n_pad / BN;
-        P.ncpt = d.span_pad / 32;
+        P.ncpt = d.span_pad / KC;
         P.ktot = d.KH * d.KW * d.span_pad;
         P.div_howo = make_fastdiv((unsigned)(d.Ho * d.Wo));
         P.div_wo = make_fastdiv((unsigned)d.Wo);
-        P.in_bytes = (unsigned)((long long)d.B * d.H * d.W * d.in_cstride * 4);
-        P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * 4);
+        P.in_bytes = (unsigned)((long long)d.B * d.H * d.W * d.in_cstride * ES);
+        P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * ES);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
-        int splits = (workspace && !d.out_f16) ? choose_splits(launch_tiles, chunks) : 1;
+        int splits = workspace ? choose_splits(launch_tiles, chunks) : 1;     // (the reduce kernel stores half too)
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
         if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
         P.cps = (chunks + splits - 1) / splits;
@@ -775,9 +834,20 @@ extern "C" int ml_conv2d_ntile(int32_t cout, int32_t tile) {
 extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 64ll << 20; }
 
 int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d);                               // conv1x1_pipe.hip
+// fp16 storage: the persistent kernel takes every 1x1 problem it can run, except those the generic kernel would cut
+// along K (few tiles, long K: the laterals of the coarse pyramid levels, the image-pooling branch) -- it has no split-K.
+// A residual (the ResNeXt conv3 of every block) is only implemented there.
+static bool pipe_preferred_half(const ml_conv2d_desc &d) {
+    if (d.residual || d.tile == 4) return true;
+    const long long M = (long long)d.B * d.Ho * d.Wo;
+    const long long tiles = ((M + 127) / 128) * ((d.cout + 127) / 128);
+    return tiles >= 192 || d.span / 64 < 16;
+}
+
 extern "C" int ml_conv2d_uses_pipe(const ml_conv2d_desc *d) {
     if (!d) return 0;
-    if (d->tile == 4 || d->math == ML_MATH_F16S) return ml_conv1x1_pipe_eligible(*d);
+    if (d->math == ML_MATH_F16S) return pipe_preferred_half(*d) && ml_conv1x1_pipe_eligible(*d);
+    if (d->tile == 4) return ml_conv1x1_pipe_eligible(*d);
     return d->tile == 0 && pipe_preferred(*d) && ml_conv1x1_pipe_eligible(*d);
 }
 
@@ -788,7 +858,8 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
-        const long long img_bytes = (long long)d.H * d.W * d.in_cstride * 4;
+        const int es_in = d.math == ML_MATH_F16S ? 2 : 4, es_out = d.out_f16 ? 2 : 4;
+        const long long img_bytes = (long long)d.H * d.W * d.in_cstride * es_in;
         const long long limit = (1ll << 31) - 16;
         long long per = img_bytes > 0 ? limit / img_bytes : d.B;
         if (per < 1) per = 1;
@@ -805,8 +876,8 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
             if (m >= cap) return -1;
             ml_conv2d_desc g = d;
             g.B = (int)(d.B - b0 < per ? d.B - b0 : per);
-            g.in = d.in + b0 * in_img;
-            g.out = d.out + b0 * out_img;
+            g.in = reinterpret_cast<const float *>(reinterpret_cast<const char *>(d.in) + b0 * in_img * es_in);
+            g.out = reinterpret_cast<float *>(reinterpret_cast<char *>(d.out) + b0 * out_img * es_out);
             if (d.residual) g.residual = d.residual + b0 * res_img;
             out[m++] = g;
         }
@@ -833,8 +904,8 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
         const long long M = (long long)d.B * d.Ho * d.Wo;
-        const int chunks = d.KH * d.KW * (d.span_pad / 32);
-        const int splits = (have_ws && !d.out_f16) ? choose_splits(tiles, chunks) : 1;
+        const int chunks = d.KH * d.KW * (d.span_pad / (d.math == ML_MATH_F16S ? 64 : 32));
+        const int splits = have_ws ? choose_splits(tiles, chunks) : 1;
         blocks += ((M + 127) / 128) * (d.n_pad / ref_bn) * splits;
     }
     const long long resident = ml_resident_blocks(2);
@@ -850,12 +921,13 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     ML_REQUIRE(descs_in != nullptr && n_in >= 1 && n_in <= MAXP, "conv2d: need 1..%d problems", MAXP);
     // the persistent 1x1 kernel has no tensor-size limit: try it before any splitting
     if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4)) {
-        const int rc0 = validate(descs_in[0]);
+        const int rc0 = validate(descs_in[0], false);
         if (rc0 != ML_OK) return rc0;
         ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16 || descs_in[0].math == ML_MATH_F16S,
                    "conv2d: unknown math mode %d", descs_in[0].math);
         int took = 0;
-        if (descs_in[0].tile == 4 || descs_in[0].math == ML_MATH_F16S || pipe_preferred(descs_in[0])) {
+        const bool half = descs_in[0].math == ML_MATH_F16S;
+        if (half ? pipe_preferred_half(descs_in[0]) : (descs_in[0].tile == 4 || pipe_preferred(descs_in[0]))) {
             const int rc = ml_conv1x1_pipe_try(descs_in[0], reinterpret_cast<hipStream_t>(stream), &took);
             if (rc != ML_OK) return rc;
             if (took) return ML_OK;
@@ -874,26 +946,34 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
         if (i == 0) t0 = t;
         ML_REQUIRE(t == t0, "conv2d: all problems of one launch must use the same tile shape");
         ML_REQUIRE(descs[i].math == descs[0].math, "conv2d: all problems of one launch must use the same math mode");
+        ML_REQUIRE(!(descs[i].math == ML_MATH_F16S && descs[i].residual),
+                   "conv2d: the fp16-storage form of the generic kernel takes no residual (only the persistent 1x1 kernel does: "
+                   "stride 1, cout %% 128 == 0, span %% 64 == 0, half output)");
     }
-    ML_REQUIRE(descs[0].math != ML_MATH_F16S,
-               "conv2d: fp16 storage (ML_MATH_F16S) is implemented for 1x1 stride-1 convs with cout %% 128 == 0, "
-               "span %% 64 == 0, cout <= 1024 only (the ResNeXt bottleneck convs)");
-    ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16, "conv2d: unknown math mode %d", descs[0].math);
+    ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16 || descs[0].math == ML_MATH_F16S,
+               "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     long long ref_tiles = -1;
     const int t = narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles);
+    if (descs[0].math == ML_MATH_F16S) {
+        switch (t) {
+            case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            default: return launch_multi<4, 1, 1, 1, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        }
+    }
     if (descs[0].math == ML_MATH_F16) {
         switch (t) {
-            case 1: return launch_multi<2, 2, 2, 2, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-            case 2: return launch_multi<2, 2, 2, 1, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-            default: return launch_multi<4, 1, 1, 1, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F16>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F16>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            default: return launch_multi<4, 1, 1, 1, ML_MATH_F16>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         }
     }
     switch (t) {
-        case 1: return launch_multi<2, 2, 2, 2, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-        case 2: return launch_multi<2, 2, 2, 1, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-        default: return launch_multi<4, 1, 1, 1, false>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        default: return launch_multi<4, 1, 1, 1, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);
     }
 }
 

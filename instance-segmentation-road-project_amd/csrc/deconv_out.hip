@@ -24,7 +24,8 @@ constexpr int ROWB = 128;                          // bytes of K per staged row 
 constexpr int DO_MAX_PROB = 4;
 
 struct DoProb {
-    const float *x, *wd, *bd, *wo, *bo;
+    const void *x, *wd;          // fp32, or IEEE half when the launch is the fp16-storage one (HALF)
+    const float *bd, *wo, *bo;
     float *out;
     long long M;                 // input pixels = rois * hw
     int hw, w, n_l, tile0;       // pixels per RoI map, map width, RoIs per image, first tile of this problem
@@ -67,11 +68,43 @@ __device__ __forceinline__ int div_small(int n, int d, float rd) {
 // where a work unit lives (all scalar)
 struct Loc {
     int pi;                      // problem index, -1 = no such unit
-    const float *x;              // first pixel row of the tile
+    const char *x;               // first pixel row of the tile
     unsigned x_bytes;            // bytes of the tile's rows that exist (rows past the problem's end read as zeros)
-    const float *w;              // Wd[pos]
+    const char *w;               // Wd[pos]
     int m0;                      // first pixel of the tile inside its problem
 };
+
+typedef _Float16 f16x8o __attribute__((ext_vector_type(8)));
+
+// One K chunk of HALF tensors (64 deep = the same 128 bytes per row): 4 k-steps of v_mfma_f32_32x32x16_f16, the lane's
+// ds_read_b128 holding the 8 halves it feeds; staging, swizzle and look-ahead loads as below.
+template <int NT, bool FIRST>
+__device__ __forceinline__ void do_chunk_h(f32x16 (&acc)[NT], const char *rd, char *wr, int x_off, int w_off, int h, int swz,
+                                           int wave, const int (&x_voff)[4], const int (&w_voff)[NT],
+                                           __amdgpu_buffer_rsrc_t rx_nx, __amdgpu_buffer_rsrc_t rw_nx, int soff) {
+    constexpr int NSLOT = 4 * NT;
+    f32x4 fx[2], fw[2][NT];
+    auto read_frags = [&](int ks, f32x4 &x, f32x4 (&w)[NT]) {
+        const int slot = ((ks * 2 + h) ^ swz) * 16;
+        x = *reinterpret_cast<const f32x4 *>(rd + x_off + slot);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const f32x4 *>(rd + w_off + t * 32 * ROWB + slot);
+    };
+    read_frags(0, fx[0], fw[0]);
+    static_for<0, NSLOT>([&](auto ic) {
+        constexpr int idx = decltype(ic)::value;             // ks * NT + t
+        constexpr int t = idx % NT, ks = idx / NT;
+        if constexpr (t == NT / 2 && ks < 3) read_frags(ks + 1, fx[(ks + 1) & 1], fw[(ks + 1) & 1]);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f16x8o a = __builtin_bit_cast(f16x8o, fw[ks & 1][t]), b = __builtin_bit_cast(f16x8o, fx[ks & 1]);
+        if constexpr (FIRST && ks == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (idx < 4) lds_dma16(rx_nx, wr + (32 * idx + 8 * wave) * ROWB, x_voff[idx], soff);
+        else if constexpr (idx < 4 + NT) lds_dma16(rw_nx, wr + (TM + 32 * (idx - 4) + 8 * wave) * ROWB, w_voff[idx - 4], soff);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
 
 // One K chunk (32 deep) of the wave's [C_mid channels x 32 pixels] slice; the next chunk's LDS-direct loads ride
 // behind the first MFMAs.  FIRST: the chain starts from C = 0.
@@ -107,16 +140,18 @@ __device__ __forceinline__ void do_chunk(f32x16 (&acc)[NT], const char *rd, char
 // A block is persistent: it walks work units (tile of 128 pixels, position) u = block, block + grid, ... and its chunk
 // stream crosses unit boundaries -- the first chunk of the next unit is fetched behind the last chunk's MFMAs and lands
 // while the 1x1 conv and the stores of the finished unit run.
-template <int NT>                                   // C_mid = 32 NT
+template <int NT, bool HALF>                        // C_mid = 32 NT; HALF: x and wd are IEEE half (fp16-storage mask head)
 __global__ void __launch_bounds__(256, NT <= 4 ? 2 : 1)
 deconv_out_kernel(const DoArgs A) {
     constexpr int CM = 32 * NT;
+    constexpr int ES = HALF ? 2 : 4;                 // bytes per element of x / wd
+    constexpr int KC = ROWB / ES;                    // K elements per chunk
     constexpr int BUFB = (TM + CM) * ROWB;
     extern __shared__ __align__(16) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int K = A.K, nk = K >> 5;
+    const int K = A.K, nk = K / KC;
     const int grid = gridDim.x;                      // a multiple of 32: a block keeps its position and its XCD slot
 
     // unit -> (tile, position): the four positions of a tile read the same pixels, so they sit on ONE XCD (block b
@@ -133,7 +168,7 @@ deconv_out_kernel(const DoArgs A) {
     auto locate = [&](int u) {
         Loc L;
         const int tile = (u >> 5) * 8 + (u & 7);
-        L.pi = -1; L.x = A.p[0].x; L.x_bytes = 0; L.w = A.p[0].wd; L.m0 = 0;
+        L.pi = -1; L.x = reinterpret_cast<const char *>(A.p[0].x); L.x_bytes = 0; L.w = reinterpret_cast<const char *>(A.p[0].wd); L.m0 = 0;
         if (tile < A.tiles) {
             int pi = 0;
             if (A.nprob > 1 && tile >= A.p[1].tile0) pi = 1;
@@ -142,10 +177,10 @@ deconv_out_kernel(const DoArgs A) {
             const DoProb P = prob(pi);
             L.pi = pi;
             L.m0 = (tile - P.tile0) * TM;
-            L.x = P.x + (long long)L.m0 * K;
+            L.x = reinterpret_cast<const char *>(P.x) + (long long)L.m0 * K * ES;
             const int rows = (int)P.M - L.m0;                 // >= 1: the tile exists
-            L.x_bytes = (unsigned)((rows < TM ? rows : TM) * K * 4);
-            L.w = P.wd + (long long)pos * CM * K;
+            L.x_bytes = (unsigned)((rows < TM ? rows : TM) * K * ES);
+            L.w = reinterpret_cast<const char *>(P.wd) + (long long)pos * CM * K * ES;
         }
         return L;
     };
@@ -162,12 +197,12 @@ deconv_out_kernel(const DoArgs A) {
     const int ld_g = (tid & 7) ^ ((ld_row >> 1) & 7);
     int x_voff[4], w_voff[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_voff[i] = (ld_row + 32 * i) * K * 4 + ld_g * 16;
+    for (int i = 0; i < 4; ++i) x_voff[i] = (ld_row + 32 * i) * K * ES + ld_g * 16;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) w_voff[i] = (ld_row + 32 * i) * K * 4 + ld_g * 16;
+    for (int i = 0; i < NT; ++i) w_voff[i] = (ld_row + 32 * i) * K * ES + ld_g * 16;
     const int swz = (r >> 1) & 7;
     const int x_off = (32 * wave + r) * ROWB, w_off = (TM + r) * ROWB;
-    const unsigned w_bytes = (unsigned)(CM * K * 4);
+    const unsigned w_bytes = (unsigned)(CM * K * ES);
 
     int u = blockIdx.x;
     Loc cur = locate(u);
@@ -204,8 +239,13 @@ deconv_out_kernel(const DoArgs A) {
             const bool more = kc + 1 < nk;            // the next chunk: of this unit, or chunk 0 of the next one (or nothing)
             const __amdgpu_buffer_rsrc_t rx_nx = more ? rx : rx_n, rw_nx = more ? rw : rw_n;
             const int soff = more ? (kc + 1) * ROWB : 0;
-            if (kc == 0) do_chunk<NT, true>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
-            else do_chunk<NT, false>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
+            if constexpr (HALF) {
+                if (kc == 0) do_chunk_h<NT, true>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
+                else do_chunk_h<NT, false>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
+            } else {
+                if (kc == 0) do_chunk<NT, true>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
+                else do_chunk<NT, false>(acc, rd, wr, x_off, w_off, h, swz, wave, x_voff, w_voff, rx_nx, rw_nx, soff);
+            }
             buf ^= 1;
         }
 
@@ -263,9 +303,9 @@ deconv_out_kernel(const DoArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last chunk's look-ahead loads were empty, but are counted)
 }
 
-template <int NT>
+template <int NT, bool HALF>
 int launch_do(const DoArgs &A, hipStream_t s) {
-    auto kern = deconv_out_kernel<NT>;
+    auto kern = deconv_out_kernel<NT, HALF>;
     const int bytes = 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * A.cp + 32 * NT + 32 + 4 * 32 * A.cp) * 4;
     static std::atomic<unsigned long long> ok{0};
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 2 * (TM + 32 * NT) * ROWB + (NT * 16 * 2 * 32 + 32 * NT + 32 + 4 * 32 * 32) * 4,
@@ -281,10 +321,11 @@ int launch_do(const DoArgs &A, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid,
-                                       int32_t ncls, int32_t cp, int32_t act_mid, int32_t act_out, void *stream) {
+static int deconv_out_entry(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid, int32_t ncls,
+                            int32_t cp, int32_t act_mid, int32_t act_out, void *stream, bool half) {
+    const int es = half ? 2 : 4, kc = half ? 64 : 32;
     ML_REQUIRE(probs && nprob >= 1 && nprob <= DO_MAX_PROB, "deconv2x2_out1x1: 1..%d problems per launch", DO_MAX_PROB);
-    ML_REQUIRE(K >= 32 && K % 32 == 0, "deconv2x2_out1x1: input channels (%d) must be a multiple of 32", K);
+    ML_REQUIRE(K >= kc && K % kc == 0, "deconv2x2_out1x1: input channels (%d) must be a multiple of %d", K, kc);
     ML_REQUIRE(c_mid == 128 || c_mid == 256, "deconv2x2_out1x1: transposed-conv filters must be 128 or 256 (got %d)", c_mid);
     ML_REQUIRE(ncls >= 1 && ncls <= 32 && cp >= ncls && cp <= 32 && (cp & (cp - 1)) == 0,
                "deconv2x2_out1x1: 1..32 classes, table column count a power of two >= classes (got %d, %d)", ncls, cp);
@@ -307,7 +348,7 @@ extern "C" int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32
                        (q.M / q.hw) % q.rois_per_image == 0,
                    "deconv2x2_out1x1: problem %d: pixels (%lld) must be whole maps of %d (width %d) for whole images of %d RoIs",
                    i, (long long)q.M, q.hw, q.w, q.rois_per_image);
-        ML_REQUIRE((long long)(TM + 256) * K * 4 < (1ll << 31), "deconv2x2_out1x1: K too large");
+        ML_REQUIRE((long long)(TM + 256) * K * es < (1ll << 31), "deconv2x2_out1x1: K too large");
         DoProb &P = A.p[i];
         P.x = q.x; P.wd = q.wd; P.bd = q.bd; P.wo = q.wo_table; P.bo = q.bo; P.out = q.out;
         P.M = q.M; P.hw = q.hw; P.w = q.w; P.n_l = q.rois_per_image; P.tile0 = tiles;
@@ -317,5 +358,16 @@ extern "C" int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32
     }
     for (int i = nprob; i < DO_MAX_PROB; ++i) A.p[i] = A.p[0];
     A.tiles = tiles;
-    return c_mid == 128 ? launch_do<4>(A, (hipStream_t)stream) : launch_do<8>(A, (hipStream_t)stream);
+    if (half) return c_mid == 128 ? launch_do<4, true>(A, (hipStream_t)stream) : launch_do<8, true>(A, (hipStream_t)stream);
+    return c_mid == 128 ? launch_do<4, false>(A, (hipStream_t)stream) : launch_do<8, false>(A, (hipStream_t)stream);
+}
+
+extern "C" int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid,
+                                       int32_t ncls, int32_t cp, int32_t act_mid, int32_t act_out, void *stream) {
+    return deconv_out_entry(probs, nprob, K, c_mid, ncls, cp, act_mid, act_out, stream, false);
+}
+
+extern "C" int ml_deconv2x2_out1x1_f16(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid,
+                                       int32_t ncls, int32_t cp, int32_t act_mid, int32_t act_out, void *stream) {
+    return deconv_out_entry(probs, nprob, K, c_mid, ncls, cp, act_mid, act_out, stream, true);
 }

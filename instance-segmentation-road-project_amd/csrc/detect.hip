@@ -724,22 +724,49 @@ __global__ void mask_distribute_kernel(const float *__restrict__ rows, int rs, i
 }
 
 // ------------------------------------------------------------------ crop_and_resize + MoldBatch(-1)
+// T = float, or _Float16 (feature maps and crops of the fp16-storage heads: same fp32 arithmetic on the stored values,
+// one rounding at the store; the RoI BOXES stay fp32 either way)
+typedef _Float16 f16x8d __attribute__((ext_vector_type(8)));
+template <class T>
 __global__ void __launch_bounds__(256)
-roi_crop_resize_kernel(const float *__restrict__ fmap, const float *__restrict__ rows, int rs, int roff,
+roi_crop_resize_kernel(const T *__restrict__ fmap, const float *__restrict__ rows, int rs, int roff,
                        const int *__restrict__ level_slots, const int *__restrict__ level_counts,
-                       float *__restrict__ roi_fmaps, float *__restrict__ roi_boxes, int Hf, int Wf, int C4, int cap,
+                       T *__restrict__ roi_fmaps, float *__restrict__ roi_boxes, int Hf, int Wf, int CV, int cap,
                        int L, int level, int n_l, int ch, int cw, float img_h, float img_w, int box_off,
                        int box_rows) {
+    constexpr int W = 16 / (int)sizeof(T);            // elements per 16-byte access
     const int j = blockIdx.x % n_l;
     const int b = blockIdx.x / n_l;
     const int cnt = level_counts[b * L + level];
-    const int C = C4 * 4;
-    float *dst = roi_fmaps + ((long long)b * n_l + j) * ch * cw * C;
+    const int C = CV * W;
+    T *dst = roi_fmaps + ((long long)b * n_l + j) * ch * cw * C;
     float *brow = roi_boxes + ((long long)b * box_rows + box_off + j) * 6;
-    const int total = ch * cw * C4;
+    const int total = ch * cw * CV;
+    auto load = [&](const T *p, float (&v)[W]) {
+        if constexpr (W == 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(p);
+            v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+        } else {
+            const f16x8d x = *reinterpret_cast<const f16x8d *>(p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+        }
+    };
+    auto store = [&](T *p, const float (&v)[W]) {
+        if constexpr (W == 4) {
+            const f32x4 x = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(p) = x;
+        } else {
+            const f16x8d x = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
+                              (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            *reinterpret_cast<f16x8d *>(p) = x;
+        }
+    };
     if (j >= cnt) {  // MoldBatch padding (misc.py:276-282): -1 for features AND boxes
-        const f32x4 m1 = {-1.f, -1.f, -1.f, -1.f};
-        for (int i = threadIdx.x; i < total; i += blockDim.x) *reinterpret_cast<f32x4 *>(dst + (long long)i * 4) = m1;
+        float m1[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) m1[e] = -1.f;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) store(dst + (long long)i * W, m1);
         if (threadIdx.x < 6) brow[threadIdx.x] = -1.f;
         return;
     }
@@ -752,27 +779,33 @@ roi_crop_resize_kernel(const float *__restrict__ fmap, const float *__restrict__
     const float x2 = (cx + bw / 2.f) / img_w, y2 = (cy + bh / 2.f) / img_h;
     const float hs = ch > 1 ? (y2 - y1) * (float)(Hf - 1) / (float)(ch - 1) : 0.f;
     const float ws = cw > 1 ? (x2 - x1) * (float)(Wf - 1) / (float)(cw - 1) : 0.f;
-    const float *img = fmap + (long long)b * Hf * Wf * C;
+    const T *img = fmap + (long long)b * Hf * Wf * C;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int c = (i % C4) * 4;
-        const int pos = i / C4;
+        const int c = (i % CV) * W;
+        const int pos = i / CV;
         const int ox = pos % cw, oy = pos / cw;
         const float in_y = ch > 1 ? y1 * (float)(Hf - 1) + (float)oy * hs : 0.5f * (y1 + y2) * (float)(Hf - 1);
         const float in_x = cw > 1 ? x1 * (float)(Wf - 1) + (float)ox * ws : 0.5f * (x1 + x2) * (float)(Wf - 1);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        float v[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = 0.f;
         if (!(in_y < 0.f || in_y > (float)(Hf - 1) || in_x < 0.f || in_x > (float)(Wf - 1))) {
             const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
             const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
             const float fy = in_y - (float)ty, fx = in_x - (float)lx;
-            const f32x4 tl = *reinterpret_cast<const f32x4 *>(img + ((long long)ty * Wf + lx) * C + c);
-            const f32x4 tr = *reinterpret_cast<const f32x4 *>(img + ((long long)ty * Wf + rx) * C + c);
-            const f32x4 bl = *reinterpret_cast<const f32x4 *>(img + ((long long)by * Wf + lx) * C + c);
-            const f32x4 br = *reinterpret_cast<const f32x4 *>(img + ((long long)by * Wf + rx) * C + c);
-            const f32x4 top = tl + (tr - tl) * fx;
-            const f32x4 bot = bl + (br - bl) * fx;
-            v = top + (bot - top) * fy;
+            float tl[W], tr[W], bl[W], br[W];
+            load(img + ((long long)ty * Wf + lx) * C + c, tl);
+            load(img + ((long long)ty * Wf + rx) * C + c, tr);
+            load(img + ((long long)by * Wf + lx) * C + c, bl);
+            load(img + ((long long)by * Wf + rx) * C + c, br);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float top = tl[e] + (tr[e] - tl[e]) * fx;
+                const float bot = bl[e] + (br[e] - bl[e]) * fx;
+                v[e] = top + (bot - top) * fy;
+            }
         }
-        *reinterpret_cast<f32x4 *>(dst + (long long)i * 4) = v;
+        store(dst + (long long)i * W, v);
     }
 }
 
@@ -853,20 +886,40 @@ extern "C" int ml_mask_distribute_i32(const float *rows, int32_t row_stride, int
     return ML_OK;
 }
 
+template <class T>
+static int roi_crop_launch(const T *fmap, const float *rows, int32_t row_stride, int32_t row_off, const int32_t *level_slots,
+                           const int32_t *level_counts, T *roi_fmaps, float *roi_boxes, int32_t B, int32_t Hf, int32_t Wf,
+                           int32_t C, int32_t cap, int32_t L, int32_t level, int32_t n_l, int32_t ch, int32_t cw, float img_h,
+                           float img_w, int32_t box_off, int32_t box_rows, void *stream) {
+    constexpr int W = 16 / (int)sizeof(T);
+    ML_REQUIRE(fmap && rows && level_slots && level_counts && roi_fmaps && roi_boxes, "roi_crop: null pointer");
+    ML_REQUIRE(row_off >= 0 && row_off + 6 <= row_stride, "roi_crop: rows must hold 6 columns from row_off");
+    ML_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && C > 0 && C % W == 0 && n_l > 0 && ch > 0 && cw > 0, "roi_crop: bad dims (C %% %d)", W);
+    ML_REQUIRE(level >= 0 && level < L && n_l <= cap && box_off >= 0 && box_off + n_l <= box_rows, "roi_crop: bad level/rows");
+    ML_REQUIRE(ml_aligned16(fmap) && ml_aligned16(roi_fmaps), "roi_crop: 16-byte alignment");
+    hipLaunchKernelGGL(roi_crop_resize_kernel<T>, dim3((unsigned)(B * n_l)), dim3(256), 0, (hipStream_t)stream, fmap, rows,
+                       row_stride, row_off, level_slots, level_counts, roi_fmaps, roi_boxes, Hf, Wf, C / W, cap, L, level, n_l, ch, cw, img_h,
+                       img_w, box_off, box_rows);
+    ML_CHECK_LAUNCH("roi_crop");
+    return ML_OK;
+}
+
 extern "C" int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int32_t row_stride, int32_t row_off,
                                       const int32_t *level_slots,
                                       const int32_t *level_counts, float *roi_fmaps, float *roi_boxes, int32_t B,
                                       int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L, int32_t level,
                                       int32_t n_l, int32_t ch, int32_t cw, float img_h, float img_w, int32_t box_off,
                                       int32_t box_rows, void *stream) {
-    ML_REQUIRE(fmap && rows && level_slots && level_counts && roi_fmaps && roi_boxes, "roi_crop: null pointer");
-    ML_REQUIRE(row_off >= 0 && row_off + 6 <= row_stride, "roi_crop: rows must hold 6 columns from row_off");
-    ML_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && C > 0 && C % 4 == 0 && n_l > 0 && ch > 0 && cw > 0, "roi_crop: bad dims");
-    ML_REQUIRE(level >= 0 && level < L && n_l <= cap && box_off >= 0 && box_off + n_l <= box_rows, "roi_crop: bad level/rows");
-    ML_REQUIRE(ml_aligned16(fmap) && ml_aligned16(roi_fmaps), "roi_crop: 16-byte alignment");
-    hipLaunchKernelGGL(roi_crop_resize_kernel, dim3((unsigned)(B * n_l)), dim3(256), 0, (hipStream_t)stream, fmap, rows,
-                       row_stride, row_off, level_slots, level_counts, roi_fmaps, roi_boxes, Hf, Wf, C / 4, cap, L, level, n_l, ch, cw, img_h,
-                       img_w, box_off, box_rows);
-    ML_CHECK_LAUNCH("roi_crop");
-    return ML_OK;
+    return roi_crop_launch<float>(fmap, rows, row_stride, row_off, level_slots, level_counts, roi_fmaps, roi_boxes, B, Hf, Wf, C,
+                                  cap, L, level, n_l, ch, cw, img_h, img_w, box_off, box_rows, stream);
+}
+
+extern "C" int ml_roi_crop_resize_f16(const void *fmap, const float *rows, int32_t row_stride, int32_t row_off,
+                                      const int32_t *level_slots, const int32_t *level_counts, void *roi_fmaps,
+                                      float *roi_boxes, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
+                                      int32_t level, int32_t n_l, int32_t ch, int32_t cw, float img_h, float img_w,
+                                      int32_t box_off, int32_t box_rows, void *stream) {
+    return roi_crop_launch<_Float16>(reinterpret_cast<const _Float16 *>(fmap), rows, row_stride, row_off, level_slots,
+                                     level_counts, reinterpret_cast<_Float16 *>(roi_fmaps), roi_boxes, B, Hf, Wf, C, cap, L,
+                                     level, n_l, ch, cw, img_h, img_w, box_off, box_rows, stream);
 }

@@ -10,9 +10,39 @@
 //   pass 1: grid (S, N*G): each block sums a slice of one chunk in fp64 (sum, sum of squares)
 //           -> workspace[(n*G+g)*S + s]   (fp64 partials: no cancellation issue in E[x^2]-mean^2)
 //   pass 2: grid (S2, N*G): each block folds the S partials, then normalises its slice.
+// Storage type T: float, or IEEE half (the heads of the fp16 path: x and y are half, 8 per 16-byte access; statistics
+// are fp64 sums of the stored values, the normalisation runs in fp32 and is rounded ONCE at the store).
+#include <type_traits>
 #include "common.h"
 
 namespace {
+
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+
+// one 16-byte access = VW<T> elements, handled as floats
+template <class T> struct VW { static constexpr int value = 16 / sizeof(T); };
+template <class T>
+__device__ __forceinline__ void vload(const T *p, float (&v)[VW<T>::value]) {
+    if constexpr (std::is_same<T, float>::value) {
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(p);
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    } else {
+        const f16x8g x = *reinterpret_cast<const f16x8g *>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+    }
+}
+template <class T>
+__device__ __forceinline__ void vstore(T *p, const float (&v)[VW<T>::value]) {
+    if constexpr (std::is_same<T, float>::value) {
+        const f32x4 x = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(p) = x;
+    } else {
+        const f16x8g x = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
+                          (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+        *reinterpret_cast<f16x8g *>(p) = x;
+    }
+}
 
 constexpr int GN_TPB = 256;
 constexpr int GN_MAX_SPLIT = 64;
@@ -24,36 +54,42 @@ constexpr int GN_ONEPASS_MAX = 4096;
 
 struct GnPlan { int S; long long slice; };
 
-// slices are multiples of 4*GN_TPB floats so every block runs whole float4 sweeps
-static GnPlan gn_plan(long long L, int NG) {
+// slices are multiples of vw*GN_TPB elements (vw = 4 floats / 8 halves per access) so every block runs whole sweeps
+static GnPlan gn_plan(long long L, int NG, int vw = 4) {
     long long want = (2048 + NG - 1) / NG;            // aim at >= 2048 blocks on the chip
     if (want < 1) want = 1;
     if (want > GN_MAX_SPLIT) want = GN_MAX_SPLIT;
-    const long long unit = 4 * GN_TPB;
+    const long long unit = (long long)vw * GN_TPB;
     long long slice = ((L + want - 1) / want + unit - 1) / unit * unit;
     int S = (int)((L + slice - 1) / slice);
     return {S, slice};
 }
 
-template <bool VEC4 = true>
-__device__ __forceinline__ void gn_stats_body(const float *__restrict__ x, double *__restrict__ ws, long long L,
+template <class T, bool VEC4 = true>
+__device__ __forceinline__ void gn_stats_body(const T *__restrict__ x, double *__restrict__ ws, long long L,
                                               long long slice, int S, int ng, int s) {
-    const float *p = x + (long long)ng * L;
+    constexpr int W = VW<T>::value;
+    const T *p = x + (long long)ng * L;
     const long long lo = (long long)s * slice;
     const long long hi = min(lo + slice, L);
     double sum = 0.0, sq = 0.0;
     if (VEC4) {
-        // a float4 is folded in fp32 first (3 adds, 4 fma), then joins the fp64 running sums: the kernel was
-        // bound by its fp64 instruction count (12 per float4), not by HBM
-        for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
-            const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
-            const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+        // a vector is folded in fp32 first (3 adds, 4 fma per 4 values), then joins the fp64 running sums: the kernel
+        // was bound by its fp64 instruction count (12 per float4), not by HBM
+        for (long long i = lo + threadIdx.x * W; i < hi; i += GN_TPB * W) {
+            float v[W];
+            vload<T>(p + i, v);
+            float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+            float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+            if constexpr (W == 8) {
+                s4 += (v[4] + v[5]) + (v[6] + v[7]);
+                q4 += fmaf(v[7], v[7], fmaf(v[6], v[6], fmaf(v[5], v[5], v[4] * v[4])));
+            }
             sum += (double)s4;
             sq += (double)q4;
         }
     } else {
-        for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) { const double d = p[i]; sum += d; sq += d * d; }
+        for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) { const double d = (double)(float)p[i]; sum += d; sq += d * d; }
     }
     // wave reduce (64 lanes) then across the 4 waves
 #pragma unroll
@@ -74,17 +110,18 @@ __device__ __forceinline__ void gn_stats_body(const float *__restrict__ x, doubl
     }
 }
 
-template <bool VEC4>
-__global__ void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, long long L, long long slice,
+template <class T, bool VEC4>
+__global__ void gn_stats_kernel(const T *__restrict__ x, double *__restrict__ ws, long long L, long long slice,
                                 int S) {
-    gn_stats_body<VEC4>(x, ws, L, slice, S, blockIdx.y, blockIdx.x);
+    gn_stats_body<T, VEC4>(x, ws, L, slice, S, blockIdx.y, blockIdx.x);
 }
 
-template <bool VEC4 = true>
-__device__ __forceinline__ void gn_apply_body(const float *x, float *y, const float *__restrict__ gamma,
+template <class T, bool VEC4 = true>
+__device__ __forceinline__ void gn_apply_body(const T *x, T *y, const float *__restrict__ gamma,
                                               const float *__restrict__ beta, const double *__restrict__ ws, long long L,
                                               long long slice, int S, int C, int G, float eps, int relu, int out_cs,
                                               int out_co, int ng, int s) {
+    constexpr int W = VW<T>::value;
     const int g = ng % G;
     const int cg = C / G;
     double sum = 0, sq = 0;
@@ -97,39 +134,53 @@ __device__ __forceinline__ void gn_apply_body(const float *x, float *y, const fl
     if (vard < 0) vard = 0;
     const float mean = (float)meand;
     const float rstd = (float)(1.0 / sqrt(vard + (double)eps));
-    const float *p = x + (long long)ng * L;
+    const T *p = x + (long long)ng * L;
     const bool dense = (out_cs == C);
     // dense: y has x's layout.  sliced: element f of the sample -> y[n][f / C][out_co + f % C]
     const long long HWC = L * G;
-    float *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
+    T *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
     const long long lo = (long long)s * slice;
     const long long hi = min(lo + slice, L);
     // flat index inside the sample = g*L + i ; channel = that mod C
     const long long gbase = (long long)g * L;
-    if (VEC4 && (cg % 4 == 0) && HWC < (1ll << 31)) {
-        // Hot form: a float4 never straddles a gamma period (cg % 4 == 0) and the flat index fits 32 bits, so
+    if (VEC4 && (cg % W == 0) && HWC < (1ll << 31)) {
+        // Hot form: a vector never straddles a gamma period (cg % W == 0) and the flat index fits 32 bits, so
         // channel / pixel / gamma offset advance incrementally -- no division or modulo inside the loop (the
-        // 64-bit `%` and `/` per float4 made this pass VALU-bound)
+        // 64-bit `%` and `/` per vector made this pass VALU-bound)
         const unsigned Cu = (unsigned)C, cgu = (unsigned)cg;
-        const long long i0 = lo + threadIdx.x * 4;
+        const long long i0 = lo + threadIdx.x * W;
         const unsigned f0 = (unsigned)(gbase + i0);
         unsigned c0 = f0 % Cu, pix = f0 / Cu, cm = c0 % cgu;
-        const unsigned stepc = (GN_TPB * 4u) % Cu, steppix = (GN_TPB * 4u) / Cu, stepm = (GN_TPB * 4u) % cgu;
+        const unsigned stepc = (GN_TPB * (unsigned)W) % Cu, steppix = (GN_TPB * (unsigned)W) / Cu, stepm = (GN_TPB * (unsigned)W) % cgu;
         const float *gp = gamma ? gamma + g * cg : nullptr;
         const float *bp = beta ? beta + g * cg : nullptr;
-        for (long long i = i0; i < hi; i += GN_TPB * 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
-            f32x4 o;
+        for (long long i = i0; i < hi; i += GN_TPB * W) {
+            float v[W], o[W];
+            vload<T>(p + i, v);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd;
-            if (gp) o *= *reinterpret_cast<const f32x4 *>(gp + cm);
-            if (bp) o += *reinterpret_cast<const f32x4 *>(bp + cm);
+            for (int e = 0; e < W; ++e) o[e] = (v[e] - mean) * rstd;
+            if (gp) {
+#pragma unroll
+                for (int e4 = 0; e4 < W; e4 += 4) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(gp + cm + e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e4 + e] *= gv[e];
+                }
+            }
+            if (bp) {
+#pragma unroll
+                for (int e4 = 0; e4 < W; e4 += 4) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bp + cm + e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e4 + e] += bv[e];
+                }
+            }
             if (relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                for (int e = 0; e < W; ++e) o[e] = fmaxf(o[e], 0.f);
             }
-            if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
-            else *reinterpret_cast<f32x4 *>(q + (long long)pix * out_cs + c0) = o;
+            if (dense) vstore<T>(q + i, o);
+            else vstore<T>(q + (long long)pix * out_cs + c0, o);
             c0 += stepc;
             pix += steppix;
             if (c0 >= Cu) { c0 -= Cu; ++pix; }
@@ -137,12 +188,12 @@ __device__ __forceinline__ void gn_apply_body(const float *x, float *y, const fl
             if (cm >= cgu) cm -= cgu;
         }
     } else if (VEC4) {
-        for (long long i = lo + threadIdx.x * 4; i < hi; i += GN_TPB * 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + i);
+        for (long long i = lo + threadIdx.x * W; i < hi; i += GN_TPB * W) {
+            float v[W], o[W];
+            vload<T>(p + i, v);
             const int c0 = (int)((gbase + i) % C);
-            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < W; ++e) {
                 int c = c0 + e;
                 if (c >= C) c -= C;
                 const int j = g * cg + (c % cg);
@@ -151,28 +202,28 @@ __device__ __forceinline__ void gn_apply_body(const float *x, float *y, const fl
                 if (beta) t += beta[j];
                 o[e] = relu ? fmaxf(t, 0.f) : t;
             }
-            if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
-            else *reinterpret_cast<f32x4 *>(q + ((gbase + i) / C) * out_cs + c0) = o;
+            if (dense) vstore<T>(q + i, o);
+            else vstore<T>(q + ((gbase + i) / C) * out_cs + c0, o);
         }
     } else {
         for (long long i = lo + threadIdx.x; i < hi; i += GN_TPB) {
             const int c = (int)((gbase + i) % C);
             const int j = g * cg + (c % cg);
-            float t = (p[i] - mean) * rstd;
+            float t = ((float)p[i] - mean) * rstd;
             if (gamma) t *= gamma[j];
             if (beta) t += beta[j];
             const float r = relu ? fmaxf(t, 0.f) : t;
-            if (dense) q[i] = r;
-            else q[((gbase + i) / C) * out_cs + c] = r;
+            if (dense) q[i] = (T)r;
+            else q[((gbase + i) / C) * out_cs + c] = (T)r;
         }
     }
 }
 
-template <bool VEC4>
-__global__ void gn_apply_kernel(const float *x, float *y, const float *__restrict__ gamma,
+template <class T, bool VEC4>
+__global__ void gn_apply_kernel(const T *x, T *y, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const double *__restrict__ ws, long long L,
                                 long long slice, int S, int C, int G, float eps, int relu, int out_cs, int out_co) {
-    gn_apply_body<VEC4>(x, y, gamma, beta, ws, L, slice, S, C, G, eps, relu, out_cs, out_co, blockIdx.y, blockIdx.x);
+    gn_apply_body<T, VEC4>(x, y, gamma, beta, ws, L, slice, S, C, G, eps, relu, out_cs, out_co, blockIdx.y, blockIdx.x);
 }
 
 // ---- one-pass form: the chunk lives in registers.  Block (TPB threads) = one (sample, chunk).
@@ -190,23 +241,26 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return t;
 }
 
-template <int TPB, int VPT>
-__device__ __forceinline__ void gn_onepass_body(const float *__restrict__ x, float *__restrict__ y,
+template <class T, int TPB, int VPT>
+__device__ __forceinline__ void gn_onepass_body(const T *__restrict__ x, T *__restrict__ y,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta, int L,
                                                 int C, int G, float eps, int relu, int out_cs, int out_co, int ng) {
+    constexpr int W = VW<T>::value;
     __shared__ double red[TPB / 64];
     const int g = ng % G;
     const int cg = C / G;
-    const float *p = x + (long long)ng * L;
-    f32x4 v[VPT];
+    const T *p = x + (long long)ng * L;
+    float v[VPT][W];
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-        const int i = (k * TPB + threadIdx.x) * 4;
-        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int i = (k * TPB + threadIdx.x) * W;
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[k][e] = 0.f;
         if (i < L) {
-            v[k] = *reinterpret_cast<const f32x4 *>(p + i);
+            vload<T>(p + i, v[k]);
             sum += ((double)v[k][0] + (double)v[k][1]) + ((double)v[k][2] + (double)v[k][3]);
+            if constexpr (W == 8) sum += ((double)v[k][4] + (double)v[k][5]) + ((double)v[k][6] + (double)v[k][7]);
         }
     }
     const double meand = block_sum<TPB>(sum, red) / (double)L;
@@ -214,26 +268,26 @@ __device__ __forceinline__ void gn_onepass_body(const float *__restrict__ x, flo
     double sq = 0.0;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-        const int i = (k * TPB + threadIdx.x) * 4;
+        const int i = (k * TPB + threadIdx.x) * W;
         if (i < L) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e] - meand; sq += d * d; }
+            for (int e = 0; e < W; ++e) { const double d = (double)v[k][e] - meand; sq += d * d; }
         }
     }
     const double vard = block_sum<TPB>(sq, red) / (double)L;
     const float rstd = (float)(1.0 / sqrt(vard + (double)eps));
     const bool dense = (out_cs == C);
     const long long HWC = (long long)L * G;
-    float *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
+    T *q = dense ? y + (long long)ng * L : y + (long long)(ng / G) * (HWC / C) * out_cs + out_co;
     const long long gbase = (long long)g * L;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-        const int i = (k * TPB + threadIdx.x) * 4;
+        const int i = (k * TPB + threadIdx.x) * W;
         if (i >= L) continue;
         const int c0 = (int)((gbase + i) % C);
-        f32x4 o;
+        float o[W];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < W; ++e) {
             int c = c0 + e;
             if (c >= C) c -= C;
             const int j = g * cg + (c % cg);
@@ -242,22 +296,22 @@ __device__ __forceinline__ void gn_onepass_body(const float *__restrict__ x, flo
             if (beta) t += beta[j];
             o[e] = relu ? fmaxf(t, 0.f) : t;
         }
-        if (dense) *reinterpret_cast<f32x4 *>(q + i) = o;
-        else *reinterpret_cast<f32x4 *>(q + ((gbase + i) / C) * out_cs + c0) = o;
+        if (dense) vstore<T>(q + i, o);
+        else vstore<T>(q + ((gbase + i) / C) * out_cs + c0, o);
     }
 }
 
-template <int TPB, int VPT>
+template <class T, int TPB, int VPT>
 __global__ void __launch_bounds__(TPB)
-gn_onepass_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
+gn_onepass_kernel(const T *__restrict__ x, T *__restrict__ y, const float *__restrict__ gamma,
                   const float *__restrict__ beta, int L, int C, int G, float eps, int relu, int out_cs, int out_co) {
-    gn_onepass_body<TPB, VPT>(x, y, gamma, beta, L, C, G, eps, relu, out_cs, out_co, blockIdx.x);
+    gn_onepass_body<T, TPB, VPT>(x, y, gamma, beta, L, C, G, eps, relu, out_cs, out_co, blockIdx.x);
 }
 
-template <int TPB, int VPT>
-void launch_onepass(const float *x, float *y, const float *gamma, const float *beta, int NG, int L, int C, int G,
+template <class T, int TPB, int VPT>
+void launch_onepass(const T *x, T *y, const float *gamma, const float *beta, int NG, int L, int C, int G,
                     float eps, int relu, int out_cs, int out_co, hipStream_t s) {
-    hipLaunchKernelGGL((gn_onepass_kernel<TPB, VPT>), dim3(NG), dim3(TPB), 0, s, x, y, gamma, beta, L, C, G, eps, relu,
+    hipLaunchKernelGGL((gn_onepass_kernel<T, TPB, VPT>), dim3(NG), dim3(TPB), 0, s, x, y, gamma, beta, L, C, G, eps, relu,
                        out_cs, out_co);
 }
 
@@ -269,8 +323,8 @@ void launch_onepass(const float *x, float *y, const float *gamma, const float *b
 // (2) one launch that applies those AND normalises the small-chunk problems in their register-resident one-pass
 // form.  Same per-problem arithmetic as the single-problem kernels (bit-identical results).
 struct GnProb {
-    const float *x;
-    float *y;
+    const void *x;            // T = float or _Float16 (one type per launch)
+    void *y;
     const float *gamma, *beta;
     double *ws;               // partials of this problem (two-pass only)
     long long L, slice;
@@ -283,30 +337,35 @@ struct GnMulti {
     GnProb p[ML_GN_MAX_PROBLEMS];
 };
 
+template <class T>
 __global__ void __launch_bounds__(GN_TPB)
 gn_multi_stats_kernel(const GnMulti A) {
     int pi = 0;
     while (pi + 1 < A.n && (int)blockIdx.x >= A.start[pi + 1]) ++pi;
     const GnProb &P = A.p[pi];
     const int id = blockIdx.x - A.start[pi];
-    gn_stats_body(P.x, P.ws, P.L, P.slice, P.S, id / P.S, id % P.S);
+    gn_stats_body<T>(reinterpret_cast<const T *>(P.x), P.ws, P.L, P.slice, P.S, id / P.S, id % P.S);
 }
 
+template <class T>
 __global__ void __launch_bounds__(GN_TPB)
 gn_multi_apply_kernel(const GnMulti A) {
     int pi = 0;
     while (pi + 1 < A.n && (int)blockIdx.x >= A.start[pi + 1]) ++pi;
     const GnProb &P = A.p[pi];
     const int id = blockIdx.x - A.start[pi];
+    const T *x = reinterpret_cast<const T *>(P.x);
+    T *y = reinterpret_cast<T *>(P.y);
     if (P.onepass_vpt == 0) {
-        gn_apply_body(P.x, P.y, P.gamma, P.beta, P.ws, P.L, P.slice, P.S, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co,
-                      id / P.S, id % P.S);
+        gn_apply_body<T>(x, y, P.gamma, P.beta, P.ws, P.L, P.slice, P.S, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co,
+                         id / P.S, id % P.S);
     } else if (P.onepass_vpt == 1) {
-        gn_onepass_body<GN_TPB, 1>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+        gn_onepass_body<T, GN_TPB, 1>(x, y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
     } else if (P.onepass_vpt == 2) {
-        gn_onepass_body<GN_TPB, 2>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+        gn_onepass_body<T, GN_TPB, 2>(x, y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
     } else {
-        gn_onepass_body<GN_TPB, 4>(P.x, P.y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
+        if constexpr (std::is_same<T, float>::value)
+            gn_onepass_body<T, GN_TPB, 4>(x, y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
     }
 }
 
@@ -316,7 +375,7 @@ extern "C" int64_t ml_groupnorm_workspace_bytes(int32_t N, int32_t G) {
     return (int64_t)N * G * GN_MAX_SPLIT * 2 * (int64_t)sizeof(double);
 }
 
-static int gn_validate(const float *x, float *y, int32_t N, int64_t HWC, int32_t C, int32_t G, int32_t out_cstride,
+static int gn_validate(const void *x, void *y, int32_t N, int64_t HWC, int32_t C, int32_t G, int32_t out_cstride,
                        int32_t out_coff) {
     ML_REQUIRE(x && y, "groupnorm: null pointer");
     ML_REQUIRE(N > 0 && HWC > 0 && C > 0 && G > 0, "groupnorm: bad dims");
@@ -329,10 +388,9 @@ static int gn_validate(const float *x, float *y, int32_t N, int64_t HWC, int32_t
     return ML_OK;
 }
 
-extern "C" int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
-                                      void *stream) {
-    ML_REQUIRE(descs && n >= 1 && n <= ML_GN_MAX_PROBLEMS && workspace, "groupnorm_multi: need 1..%d problems and a workspace",
-               ML_GN_MAX_PROBLEMS);
+template <class T>
+static int gn_multi(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes, void *stream) {
+    constexpr int W = VW<T>::value;
     GnMulti st, ap;
     st.n = 0;
     ap.n = n;
@@ -341,22 +399,22 @@ extern "C" int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *
         const ml_gn_desc &d = descs[i];
         if (int rc = gn_validate(d.x, d.y, d.N, d.HWC, d.C, d.G, d.out_cstride, d.out_coff)) return rc;
         const long long L = d.HWC / d.G;
-        const bool vec4 = (L % 4 == 0) && (d.C % 4 == 0) && (d.out_cstride % 4 == 0) && (d.out_coff % 4 == 0) &&
-                          ml_aligned16(d.x) && ml_aligned16(d.y);
-        ML_REQUIRE(vec4, "groupnorm_multi: problem %d needs 16-byte aligned tensors and chunk / channel counts that are "
-                   "multiples of 4 (use ml_groupnorm_chunk_f32 otherwise)", i);
+        const bool vec = (L % W == 0) && (d.C % W == 0) && (d.out_cstride % W == 0) && (d.out_coff % W == 0) &&
+                         ml_aligned16(d.x) && ml_aligned16(d.y);
+        ML_REQUIRE(vec, "groupnorm_multi: problem %d needs 16-byte aligned tensors and chunk / channel counts that are "
+                   "multiples of %d (use ml_groupnorm_chunk_f32 / _f16 otherwise)", i, W);
         GnProb P;
         P.x = d.x; P.y = d.y; P.gamma = d.gamma; P.beta = d.beta;
         P.L = L; P.NG = d.N * d.G; P.C = d.C; P.G = d.G; P.relu = d.relu; P.out_cs = d.out_cstride; P.out_co = d.out_coff;
         P.eps = d.eps;
         P.ws = nullptr; P.S = 1; P.slice = L; P.onepass_vpt = 0;
         if (L <= GN_ONEPASS_MAX) {
-            const int v4 = (int)((L + 3) / 4);
-            P.onepass_vpt = v4 <= 256 ? 1 : (v4 <= 512 ? 2 : 4);
+            const int vn = (int)((L + W - 1) / W);
+            P.onepass_vpt = vn <= 256 ? 1 : (vn <= 512 ? 2 : 4);
             ap.start[i] = (int)ab;
             ab += P.NG;
         } else {
-            const GnPlan plan = gn_plan(L, P.NG);
+            const GnPlan plan = gn_plan(L, P.NG, W);
             P.S = plan.S; P.slice = plan.slice;
             const long long bytes = (long long)P.NG * P.S * 2 * (long long)sizeof(double);
             ML_REQUIRE(ws_off + bytes <= workspace_bytes, "groupnorm_multi: workspace too small (%lld bytes needed so far)",
@@ -375,48 +433,67 @@ extern "C" int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *
     st.start[st.n] = (int)sb;
     ap.start[n] = (int)ab;
     hipStream_t s = (hipStream_t)stream;
-    if (st.n > 0) hipLaunchKernelGGL(gn_multi_stats_kernel, dim3((unsigned)sb), dim3(GN_TPB), 0, s, st);
-    hipLaunchKernelGGL(gn_multi_apply_kernel, dim3((unsigned)ab), dim3(GN_TPB), 0, s, ap);
+    if (st.n > 0) hipLaunchKernelGGL(gn_multi_stats_kernel<T>, dim3((unsigned)sb), dim3(GN_TPB), 0, s, st);
+    hipLaunchKernelGGL(gn_multi_apply_kernel<T>, dim3((unsigned)ab), dim3(GN_TPB), 0, s, ap);
     ML_CHECK_LAUNCH("groupnorm_multi");
+    return ML_OK;
+}
+
+extern "C" int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes,
+                                      void *stream) {
+    ML_REQUIRE(descs && n >= 1 && n <= ML_GN_MAX_PROBLEMS && workspace, "groupnorm_multi: need 1..%d problems and a workspace",
+               ML_GN_MAX_PROBLEMS);
+    for (int i = 1; i < n; ++i)
+        ML_REQUIRE(descs[i].dtype == descs[0].dtype, "groupnorm_multi: the problems of one launch must share the storage type");
+    ML_REQUIRE(descs[0].dtype == 0 || descs[0].dtype == 1, "groupnorm_multi: dtype must be 0 (float) or 1 (half)");
+    return descs[0].dtype ? gn_multi<_Float16>(descs, n, workspace, workspace_bytes, stream)
+                          : gn_multi<float>(descs, n, workspace, workspace_bytes, stream);
+}
+
+template <class T>
+static int gn_single(const T *x, T *y, const float *gamma, const float *beta, int32_t N, int64_t HWC, int32_t C, int32_t G,
+                     float eps, int32_t relu, int32_t out_cstride, int32_t out_coff, void *workspace, void *stream) {
+    constexpr int W = VW<T>::value;
+    ML_REQUIRE(workspace, "groupnorm: null pointer");
+    if (int rc = gn_validate(x, y, N, HWC, C, G, out_cstride, out_coff)) return rc;
+    const long long L = HWC / G;
+    const bool vec = (L % W == 0) && (C % W == 0) && (out_cstride % W == 0) && (out_coff % W == 0) &&
+                     ml_aligned16(x) && ml_aligned16(y);
+    const GnPlan plan = gn_plan(L, N * G, vec ? W : 4);
+    hipStream_t s = (hipStream_t)stream;
+    double *ws = reinterpret_cast<double *>(workspace);
+    const dim3 grid(plan.S, N * G);
+    if (vec && L <= GN_ONEPASS_MAX) {
+        // one pass, chunk in registers: vectors per thread chosen so that 256 * VPT * W >= L
+        const int NG = N * G, Li = (int)L;
+        const int vn = (Li + W - 1) / W;
+#define GN1(TPB, VPT) launch_onepass<T, TPB, VPT>(x, y, gamma, beta, NG, Li, C, G, eps, relu, out_cstride, out_coff, s)
+        if (vn <= 256) GN1(256, 1);
+        else if (vn <= 512) GN1(256, 2);
+        else if constexpr (W == 4) GN1(256, 4);
+#undef GN1
+    } else if (vec) {
+        hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
+        hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S, C,
+                           G, eps, relu, out_cstride, out_coff);
+    } else {
+        hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
+        hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S,
+                           C, G, eps, relu, out_cstride, out_coff);
+    }
+    ML_CHECK_LAUNCH("groupnorm");
     return ML_OK;
 }
 
 extern "C" int ml_groupnorm_chunk_f32(const float *x, float *y, const float *gamma, const float *beta, int32_t N,
                                       int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu, int32_t out_cstride,
                                       int32_t out_coff, void *workspace, void *stream) {
-    ML_REQUIRE(x && y && workspace, "groupnorm: null pointer");
-    ML_REQUIRE(N > 0 && HWC > 0 && C > 0 && G > 0, "groupnorm: bad dims");
-    ML_REQUIRE(C >= G, "groupnorm: Number of groups (%d) cannot be more than the number of channels (%d).", G, C);
-    ML_REQUIRE(C % G == 0, "groupnorm: Number of groups (%d) must be a multiple of the number of channels (%d).", G, C);
-    ML_REQUIRE(HWC % C == 0 && HWC % G == 0, "groupnorm: H*W*C (%lld) must be divisible by C and by G", (long long)HWC);
-    ML_REQUIRE((long long)N * G < 65536, "groupnorm: N*G too large for grid.y");
-    const long long L = HWC / G;
-    const GnPlan plan = gn_plan(L, N * G);
-    ML_REQUIRE(out_cstride >= C && out_coff >= 0 && out_coff + C <= out_cstride, "groupnorm: bad output slice");
-    ML_REQUIRE(out_cstride == C ? out_coff == 0 : true, "groupnorm: dense output must have out_coff 0");
-    const bool vec4 = (L % 4 == 0) && (C % 4 == 0) && (out_cstride % 4 == 0) && (out_coff % 4 == 0) &&
-                      ml_aligned16(x) && ml_aligned16(y);
-    hipStream_t s = (hipStream_t)stream;
-    double *ws = reinterpret_cast<double *>(workspace);
-    const dim3 grid(plan.S, N * G);
-    if (vec4 && L <= GN_ONEPASS_MAX) {
-        // one pass, chunk in registers: float4-per-thread chosen so that 256 * VPT * 4 >= L
-        const int NG = N * G, Li = (int)L;
-        const int v4 = (Li + 3) / 4;
-#define GN1(TPB, VPT) launch_onepass<TPB, VPT>(x, y, gamma, beta, NG, Li, C, G, eps, relu, out_cstride, out_coff, s)
-        if (v4 <= 256) GN1(256, 1);
-        else if (v4 <= 512) GN1(256, 2);
-        else GN1(256, 4);
-#undef GN1
-    } else if (vec4) {
-        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S, C,
-                           G, eps, relu, out_cstride, out_coff);
-    } else {
-        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_TPB), 0, s, x, ws, L, plan.slice, plan.S);
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_TPB), 0, s, x, y, gamma, beta, ws, L, plan.slice, plan.S,
-                           C, G, eps, relu, out_cstride, out_coff);
-    }
-    ML_CHECK_LAUNCH("groupnorm");
-    return ML_OK;
+    return gn_single<float>(x, y, gamma, beta, N, HWC, C, G, eps, relu, out_cstride, out_coff, workspace, stream);
+}
+
+extern "C" int ml_groupnorm_chunk_f16(const void *x, void *y, const float *gamma, const float *beta, int32_t N,
+                                      int64_t HWC, int32_t C, int32_t G, float eps, int32_t relu, int32_t out_cstride,
+                                      int32_t out_coff, void *workspace, void *stream) {
+    return gn_single<_Float16>(reinterpret_cast<const _Float16 *>(x), reinterpret_cast<_Float16 *>(y), gamma, beta, N, HWC, C,
+                               G, eps, relu, out_cstride, out_coff, workspace, stream);
 }

