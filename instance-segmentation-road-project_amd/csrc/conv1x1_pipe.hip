@@ -60,7 +60,8 @@ struct PipeArgs {
     int K, N;                                // elements
     int in_cs, in_coff, out_cs, out_coff;    // elements; res shares out_cs / out_coff (checked by the launcher)
     int panels, NB, grid;
-    int units, gshift, NBG;                  // work unit = (panel, group of NBG consecutive N tiles): unit u -> panel u >> gshift
+    int units, gshift, NBG;                  // work unit = (panel, group of NBG consecutive N tiles); 2^gshift groups per panel
+    int xcd_map;                             // 1: the groups of one panel run at the same time on ONE XCD (see the kernel)
     float lo, hi;                            // activation as a clamp
 };
 
@@ -94,7 +95,7 @@ __device__ __forceinline__ i32x4 rsrc_words(const void *ptr, long long off, long
 
 // which tile a cursor points at; advanced with scalar adds only
 struct Cursor {
-    int u, nt;           // work unit and N tile; u >= units: past the end (all its resources are empty)
+    int u, nt;           // M panel and N tile; u >= panels: past the end (all its resources are empty)
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
@@ -319,27 +320,40 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     const long long in_total = A.M * (long long)A.in_cs * ES;
     const long long out_total = A.M * (long long)A.out_cs * ES;
     const long long w_total = (long long)A.N * A.K * ES;
+    // Which (panel, N-tile group) this block works on.  A block keeps ONE group for its whole life and walks panels
+    // panel0, panel0 + step, ...  Two maps, the same work either way:
+    //   plain   : block b -> group b & gmask, panel0 = b >> gshift (adjacent blocks = adjacent groups of one panel, which
+    //             the dispatcher deals to DIFFERENT XCDs);
+    //   xcd_map : blocks with equal b & 7 share an XCD and its L2 -- slot j = b >> 3 of XCD x = b & 7 takes group j & gmask
+    //             of panel x * ppx + (j >> gshift): the 2^gshift groups of a panel run side by side on ONE XCD, so the
+    //             panel's activations come from beyond L2 once and from L2 for the other groups.  (Measured before: one
+    //             block walking a panel's N tiles one after the other re-fetched the panel for EVERY tile -- 64 blocks per
+    //             XCD stream 12+ MB through its 4 MB L2 between two tiles; gpurun_out/shape_pmc)
     const int gmask = (1 << A.gshift) - 1;
-    auto panel_of = [&](Cursor c) { return c.u >> A.gshift; };
-    auto res_a = [&](Cursor c) { return rsrc_at(A.in, (long long)panel_of(c) * BM * A.in_cs * ES, c.u < A.units ? in_total : 0); };
-    auto res_b = [&](Cursor c) { return rsrc_at(A.wgt, (long long)c.nt * BN * A.K * ES, c.u < A.units ? w_total : 0); };
+    const int step = A.grid >> A.gshift;                       // panels in flight per round
+    const int bid = (int)blockIdx.x;
+    const int slot = bid >> 3, ppx = step >> 3;
+    const int group = A.xcd_map ? (slot & gmask) : (bid & gmask);
+    const int panel0 = A.xcd_map ? (bid & 7) * ppx + (slot >> A.gshift) : (bid >> A.gshift);
+    auto panel_of = [&](Cursor c) { return c.u; };
+    auto res_a = [&](Cursor c) { return rsrc_at(A.in, (long long)panel_of(c) * BM * A.in_cs * ES, c.u < A.panels ? in_total : 0); };
+    auto res_b = [&](Cursor c) { return rsrc_at(A.wgt, (long long)c.nt * BN * A.K * ES, c.u < A.panels ? w_total : 0); };
     auto tile_off = [&](Cursor c) { return ((long long)panel_of(c) * BM * A.out_cs + (long long)c.nt * BN) * ES; };
     // rows past M must fall outside: the extent is counted from the tile's first element
-    auto res_o = [&](Cursor c) { return rsrc_at(A.out, tile_off(c), c.u < A.units ? out_total : 0); };
-    auto res_words = [&](Cursor c) { return rsrc_words(A.res, tile_off(c), (HAS_RES && c.u < A.units) ? out_total : 0); };
-    auto first_nt = [&](int u) { return (u & gmask) * A.NBG; };
+    auto res_o = [&](Cursor c) { return rsrc_at(A.out, tile_off(c), c.u < A.panels ? out_total : 0); };
+    auto res_words = [&](Cursor c) { return rsrc_words(A.res, tile_off(c), (HAS_RES && c.u < A.panels) ? out_total : 0); };
+    const int nt0 = group * A.NBG;
     auto advance = [&](Cursor c) {
         Cursor n = c;
-        if (n.nt + 1 < first_nt(n.u) + A.NBG) { ++n.nt; } else { n.u += A.grid; n.nt = first_nt(n.u); }
+        if (n.nt + 1 < nt0 + A.NBG) { ++n.nt; } else { n.u += step; n.nt = nt0; }
         return n;
     };
     // LDS: [2 staging buffers][4 wave-private transposition scratches][bias of this block's N tiles].  A block only
-    // ever works on ONE group of NBG N tiles (unit u -> group u & gmask, and u advances by the grid size, a multiple
+    // ever works on ONE group of NBG N tiles (see the maps above: the grid size is a multiple of the group count, the
     // of the group count).  The bias is read with ds_read at a tile switch: a global load there would be waited for
     // with vmcnt(0) while LDS-direct loads are in flight.
     char *scratch = lds + NSTAGE * BUFB + S.wave_u * SCRB;
     float *lds_bias = reinterpret_cast<float *>(lds + NSTAGE * BUFB + 4 * SCRB);
-    const int nt0 = first_nt((int)blockIdx.x);
     for (int i = tid; i < A.NBG * BN; i += 256) lds_bias[i] = A.bias ? A.bias[nt0 * BN + i] : 0.f;
     __syncthreads();
     auto load_bias = [&](Cursor c, f32x4 (&bv)[2][NB4]) {
@@ -350,8 +364,8 @@ conv1x1_pipe_kernel(const PipeArgs A) {
                 bv[ni][k] = *reinterpret_cast<const f32x4 *>(lds_bias + (c.nt - nt0) * BN + wn * 64 + ni * 32 + t_col + 4 * k);
     };
 
-    Cursor cur = {(int)blockIdx.x, first_nt((int)blockIdx.x)};
-    if (cur.u >= A.units) return;
+    Cursor cur = {panel0, nt0};
+    if (cur.u >= A.panels) return;
     Cursor nx = cur;                      // tile of the NEXT chunk to stage
     int kc_nx = 0;
 
@@ -377,13 +391,13 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2)) : "memory");      // chunk 0 has landed
     __builtin_amdgcn_s_barrier();
 
-    Cursor prev = {A.units, 0};           // nothing to store yet: empty resource
+    Cursor prev = {A.panels, 0};          // nothing to store yet: empty resource
     int buf = 0;
     // One tile: `acc` accumulates it, `oth` holds the previous tile's result (finished and stored during the first
     // chunk).  Returns false after the block's last tile.
     auto run_tile = [&](f32x16 (&acc)[2][2], f32x16 (&oth)[2][2]) -> bool {
         const Cursor next = advance(cur);
-        const bool has_next = next.u < A.units;
+        const bool has_next = next.u < A.panels;
         const __amdgpu_buffer_rsrc_t ro_prev = res_o(prev);
         const i32x4 rr_prev = res_words(prev);
         for (int kc = 0; kc < nk; ++kc) {
@@ -496,21 +510,34 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     // enough work units to fill every resident block (2 per CU), and at most PIPE_MAX_NBG N tiles per block: split a
     // panel's N tiles into 2^gshift groups
     const int resident = ml_resident_blocks(2);          // two 4-wave blocks per CU (512 on MI355X)
-    // Split a panel's N tiles into 2^gshift groups (a unit = one group of one panel).  Blocks are persistent and take
-    // units round-robin, so the launch lasts ceil(units / resident) units: pick the split whose last round is fullest
-    // (800 panels: 1 group -> 2 rounds for 1.56 rounds of work, 4 groups -> 7 for 6.25), the coarser one on a near tie
-    // (a coarser unit re-reads the panel's activations from L2 less often).
-    int best = -1;
-    double best_eff = -1.0;
-    for (int g = 0; (A.NB >> g) >= 1 && (A.NB % (1 << g)) == 0; ++g) {
+    // Split a panel's N tiles into 2^gshift groups (a unit = one group of one panel).  Blocks are persistent and walk
+    // panels in rounds of (grid >> gshift), so the launch lasts ceil(units / grid) units: take the splits whose last
+    // round is fullest (800 panels: 1 group -> 2 rounds for 1.56 rounds of work, 4 groups -> 7 for 6.25) and among those
+    // within 2 % the FINEST one the XCD map can place (every N tile of a panel then runs at the same time on one XCD and
+    // the panel is fetched from beyond L2 once; a block that walks several N tiles re-fetches it for each of them).
+    double eff_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, best_eff = -1.0;
+    int n_g = 0;
+    for (int g = 0; g < 8 && (A.NB >> g) >= 1 && (A.NB % (1 << g)) == 0; ++g) {
+        n_g = g + 1;
         if ((A.NB >> g) > PIPE_MAX_NBG || (1 << g) > resident) continue;
         const long long units = (long long)A.panels << g;
-        const long long rounds = (units + resident - 1) / resident;
-        const double eff = (double)units / (double)(rounds * resident);
-        if (eff > best_eff + 0.02) { best_eff = eff; best = g; }
+        const long long grid = units < resident ? units : resident / (1 << g) * (1 << g);
+        const long long rounds = (units + grid - 1) / grid;
+        eff_of[g] = (double)units / (double)(rounds * resident);
+        if (eff_of[g] > best_eff) best_eff = eff_of[g];
     }
-    if (best < 0) return ML_OK;                           // (an odd tile count above the limit: the generic kernel)
+    if (best_eff <= 0.0) return ML_OK;                    // (an odd tile count above the limit: the generic kernel)
+    int best = -1, best_map = 0;
+    for (int g = n_g - 1; g > 0 && best < 0; --g) {       // finest first, where the XCD map applies
+        if (eff_of[g] <= 0.0 || eff_of[g] < best_eff - 0.02) continue;
+        const long long units = (long long)A.panels << g;
+        const long long grid = units < resident ? units : resident / (1 << g) * (1 << g);
+        if (grid % (8ll << g) == 0) { best = g; best_map = 1; }
+    }
+    for (int g = 0; g < n_g && best < 0; ++g)             // else the coarsest (plain map)
+        if (eff_of[g] > 0.0 && eff_of[g] >= best_eff - 0.02) best = g;
     A.gshift = best;
+    A.xcd_map = best_map;
     A.NBG = A.NB >> A.gshift;
     A.units = A.panels << A.gshift;
     // a block keeps ONE group's bias in LDS and advances by the grid size: the grid must be a multiple of the group count

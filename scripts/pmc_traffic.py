@@ -19,17 +19,18 @@ def per_kernel(db, counter):
     return {k: (n, v) for k, n, v in rows}
 
 
-# The x2 FETCH correction is for WIDE coalesced streaming reads (64 lanes x 16 B = 1 KB contiguous).  The MFMA conv
-# kernels stage their operands with LDS-direct loads whose wave-instruction covers 8 rows x 128 B (rows K*4 bytes
-# apart): calibrated in THIS access pattern as the guide asks (profiles/r02b: conv1x1_pipe_kernel, residual variant --
-# known algorithmic reads 402 MB per launch, FETCH_SIZE raw 409 MB; no-residual variant 295 MB vs 280 MB; WRITE_SIZE
-# 268.4 MB vs 268.2 MB), FETCH_SIZE is exact there, so those kernels get factor 1.  (Round 1 applied x2 to them and
-# reported 1.40x "wasted" traffic that was not there.)
-FETCH_FACTOR_1 = ("conv_mfma_kernel", "conv1x1_pipe_kernel")
+# FETCH_SIZE on gfx950 reports HALF the bytes fetched (128-byte requests tallied at 64 B): the guide says so for wide
+# 16-B-per-lane reads "global_load and buffer_load ... lds alike", and scripts/calibrate/calib.hip confirms it for THIS
+# code's access patterns on a 1 GiB buffer read exactly once (no reuse, > Infinity Cache; profiles/r03_calib_pmc_fetch.md):
+# wide coalesced global loads, LDS-direct loads of 8 rows x 128 B at row pitches 128 / 512 / 2048 B, and the same
+# addresses through register loads ALL report 0.5 GiB for 1 GiB read; WRITE_SIZE reports 1 GiB for 1 GiB written.
+# So the factor is 2 for every kernel.  (Round 2 used x1 for the MFMA convs, "calibrated" on the pipelined 1x1 kernel
+# under the assumption that it reads its activations once from HBM -- it does not: with x2 that kernel moves about
+# twice its algorithmic read bytes, which is an over-fetch to fix, not a counter property.)
 
 
 def fetch_factor(kernel_name):
-    return 1 if any(t in kernel_name for t in FETCH_FACTOR_1) else 2
+    return 2
 
 
 def main():
@@ -44,8 +45,9 @@ def main():
                   "fetch_bytes_per_launch": c * 1024 * fk / n, "write_bytes_per_launch": 1024 * wk / n,
                   "hbm_bytes_per_launch": (c * 1024 * fk + 1024 * wk) / n}
     from bench import csrc_hash      # bench.py only reports `traffic` from a pass taken on the sources it was built from
-    json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); gfx950 FETCH correction x2 for wide "
-                         "coalesced streaming reads, x1 (calibrated) for the 128-byte-row LDS-direct staging of the MFMA convs",
+    json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); gfx950 FETCH correction x2 for every "
+                         "kernel (calibrated on no-reuse 1 GiB copies in this code's access patterns: "
+                         "profiles/r03_calib_pmc_fetch.md, scripts/calibrate/calib.hip)",
                "source_sha256": csrc_hash(), "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]:
         print(f"{k[:80]:80s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch x {v['dispatches']}")
