@@ -376,7 +376,9 @@ def main():
     pending = []                               # all-gathers in flight (consumed one step later)
 
     def step(collective=True):
-        outs = model(host_images.to(device, non_blocking=True) if args.host_inputs else images)
+        # (under --graph the whole forward is one replay with no host read; `defer` keeps even the output molding's read
+        # out of the loop, so forwards are enqueued back to back)
+        outs = model(host_images.to(device, non_blocking=True) if args.host_inputs else images, defer=args.graph)
         mark("forward enqueued")
         if gather is not None and collective:
             if pending:                        # the previous batch's merged detections: make them visible to this stream

@@ -38,12 +38,14 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2 };
 
-#define ML_ABI_VERSION 4              /* 2: ml_conv2d_desc gained `math` / `reserved0`
+#define ML_ABI_VERSION 5              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
                                             fp16 tensor storage
                                          4: fp16 storage in the heads: ML_MATH_F16S on the generic conv,
                                             ml_gn_desc.dtype, the *_f16 entry points of GroupNorm, resize,
-                                            depthwise conv, global mean, RoI crop and the mask-head tail  */
+                                            depthwise conv, global mean, RoI crop and the mask-head tail
+                                         5: fixed-capacity RoI batches (`live`) in conv / GroupNorm / RoI crop /
+                                            mask-head tail descriptors, ml_mold_levels_f32                */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -98,6 +100,12 @@ typedef struct ml_conv2d_desc {
     int64_t out_bstride;    /* floats between images in `out`; 0 = Ho*Wo*out_cstride (dense).
                                Lets a level's head write straight into the concatenated
                                [B, A, classes] prediction (detection.py:210-212 Reshape+Concatenate) */
+    const int32_t *live;    /* NULL, or a DEVICE int: the batch is a fixed-capacity RoI batch (the mask head run
+                               without a host read of the RoI counts, instance.py:121-134 + MoldBatch misc.py:231-286)
+                               in which image i exists iff i % live_period < max(1, *live); tiles that hold only
+                               non-existing images compute and store nothing.  Generic kernel only.        */
+    int32_t live_period;    /* RoI slots per image (B % live_period == 0); ignored when live == NULL      */
+    int32_t reserved1;
 } ml_conv2d_desc;
 
 int ml_conv2d_f32(const ml_conv2d_desc *d, void *stream);
@@ -178,6 +186,8 @@ typedef struct ml_deconv_out_problem {
     int64_t M;
     int32_t hw, w, rois_per_image, reserved0;
     int64_t out_image_stride, out_base;
+    const int32_t *live;   /* NULL, or a device int: RoI slot j of an image exists iff j < max(1, *live) (fixed-capacity
+                              batch with rois_per_image = the capacity); tiles of non-existing slots are skipped */
 } ml_deconv_out_problem;
 int ml_deconv2x2_out1x1_f32(const ml_deconv_out_problem *probs, int32_t nprob, int32_t K, int32_t c_mid, int32_t ncls,
                             int32_t cp, int32_t act_mid, int32_t act_out, void *stream);
@@ -240,6 +250,9 @@ typedef struct ml_gn_desc {
     float eps;
     int32_t dtype;                 /* 0: x / y are float; 1: x / y point to IEEE half (fp16-storage heads;
                                       HWC/G and C multiples of 8); gamma / beta are float either way */
+    const int32_t *live;           /* NULL, or a device int: sample n exists iff n % live_period < max(1, *live)
+                                      (fixed-capacity RoI batches, as ml_conv2d_desc.live); others are skipped   */
+    int32_t live_period, reserved;
 } ml_gn_desc;
 #define ML_GN_MAX_PROBLEMS 8
 int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes, void *stream);
@@ -302,13 +315,24 @@ int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int32_t row_str
                            const int32_t *level_counts, float *roi_fmaps, float *roi_boxes,
                            int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
                            int32_t level, int32_t n_l, int32_t ch, int32_t cw,
-                           float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);
+                           float img_h, float img_w, int32_t box_off, int32_t box_rows,
+                           const int32_t *live /* NULL, or a device int: with n_l = cap (no host read of the counts) only
+                                                  slots j < max(1, *live) are written (crop or -1 fill) */,
+                           void *stream);
 /* The same with fmap / roi_fmaps in IEEE half (C % 8 == 0): the mask head of the fp16 path; boxes and rows stay fp32. */
 int ml_roi_crop_resize_f16(const void *fmap, const float *rows, int32_t row_stride, int32_t row_off,
                            const int32_t *level_slots, const int32_t *level_counts, void *roi_fmaps, float *roi_boxes,
                            int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
                            int32_t level, int32_t n_l, int32_t ch, int32_t cw,
-                           float img_h, float img_w, int32_t box_off, int32_t box_rows, void *stream);
+                           float img_h, float img_w, int32_t box_off, int32_t box_rows, const int32_t *live,
+                           void *stream);
+
+/* MoldBatch + Concatenate(axis=1) of a fixed-capacity stage 2 (instance.py:222-225, misc.py:231-286): src [B, L*cap, E]
+ * holds level l's RoIs at rows l*cap ..; dst [B, sum n_l, E] receives rows [l*cap, l*cap + n_l) of every image, the
+ * levels next to each other.  n_l: L HOST ints (1 <= n_l <= cap) -- the one read of the forward, done after all of it
+ * has been enqueued.  E % 4 == 0.                                                                                 */
+int ml_mold_levels_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
+                       const int32_t *n_l, void *stream);
 
 /* x += y over n floats (n % 4 == 0): the `Add` of MobileSeparableConv2D (misc.py:92,105) */
 int ml_add_f32(float *x, const float *y, int64_t n, void *stream);

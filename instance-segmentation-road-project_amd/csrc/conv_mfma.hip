@@ -191,6 +191,15 @@ conv_mfma_kernel(const MultiArgs args) {
     if (mt >= P.MB) return;
     const int m0 = mt * BM;
     const int n0 = nt * BN;
+    // Fixed-capacity RoI batches (the mask head without a host read of the RoI counts): image i of this problem is LIVE
+    // iff i % live_period < max(1, *live).  A tile all of whose images are dead computes nothing and stores nothing
+    // (nobody reads those rows); rows of dead images inside a live tile are computed from whatever their input holds.
+    if (p.live) {
+        const int lim = max(1, *p.live);
+        const int i0 = fast_div(m0, P.div_howo) % p.live_period;
+        const int i1 = fast_div(min(m0 + BM, P.M) - 1, P.div_howo) % p.live_period;
+        if (i0 >= lim && i1 >= lim && i0 <= i1) return;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -700,6 +709,9 @@ int validate(const ml_conv2d_desc &d, bool generic = true) {
     }
     if (d.residual) ML_REQUIRE(d.res_coff + d.cout <= d.res_cstride, "conv2d: residual slice exceeds buffer");
     ML_REQUIRE(d.out_f16 == 0 || d.out_f16 == 1, "conv2d: out_f16 must be 0 or 1");
+    if (d.live)
+        ML_REQUIRE(d.live_period >= 1 && d.B % d.live_period == 0 && (long long)d.Ho * d.Wo * d.live_period >= 128,
+                   "conv2d: `live` needs live_period >= 1 dividing B and at least one 128-row tile per period");
     if (d.out_f16 && generic)
         ML_REQUIRE((d.math == ML_MATH_F16 || hs) && !d.residual && !d.shuffle2x2 && d.out_bstride == 0 && d.act != ML_ACT_SIGMOID &&
                        d.cout % 4 == 0 && d.out_cstride % 4 == 0 && d.out_coff % 4 == 0 && (((uintptr_t)d.out) & 7) == 0,
@@ -868,6 +880,7 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
             out[m++] = d;
             continue;
         }
+        if (d.live) return -2;          // (image groups would renumber the images a `live` period counts)
         const long long in_img = (long long)d.H * d.W * d.in_cstride;
         const long long out_pix = d.shuffle2x2 ? 4ll * d.Ho * d.Wo : (long long)d.Ho * d.Wo;
         const long long out_img = d.out_bstride ? d.out_bstride : out_pix * d.out_cstride;
@@ -936,6 +949,7 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     }
     ml_conv2d_desc split[MAXP];
     const int n = split_by_image_groups(descs_in, n_in, split, MAXP);
+    ML_REQUIRE(n != -2, "conv2d: a problem with `live` images must stay below 2 GiB of activations");
     ML_REQUIRE(n >= 1, "conv2d: too many >= 2 GiB activations in one launch (more than %d image groups)", MAXP);
     const ml_conv2d_desc *descs = split;
     int t0 = 0;

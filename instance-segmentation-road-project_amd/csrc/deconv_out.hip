@@ -27,6 +27,7 @@ struct DoProb {
     const void *x, *wd;          // fp32, or IEEE half when the launch is the fp16-storage one (HALF)
     const float *bd, *wo, *bo;
     float *out;
+    const int *live;             // fixed-capacity RoI batch: RoI slot j of an image exists iff j < max(1, *live); or NULL
     long long M;                 // input pixels = rois * hw
     int hw, w, n_l, tile0;       // pixels per RoI map, map width, RoIs per image, first tile of this problem
     float r_hw, r_w, r_nl;       // reciprocals (index arithmetic below corrects the rounding)
@@ -165,22 +166,33 @@ deconv_out_kernel(const DoArgs A) {
         if (pi == 3) P = A.p[3];
         return P;
     };
-    auto locate = [&](int u) {
+    // (advances `u` past units whose tile holds only RoI slots that do not exist -- fixed-capacity batches, `live`)
+    auto locate = [&](int &u) {
         Loc L;
-        const int tile = (u >> 5) * 8 + (u & 7);
         L.pi = -1; L.x = reinterpret_cast<const char *>(A.p[0].x); L.x_bytes = 0; L.w = reinterpret_cast<const char *>(A.p[0].wd); L.m0 = 0;
-        if (tile < A.tiles) {
+        for (;; u += grid) {
+            const int tile = (u >> 5) * 8 + (u & 7);
+            if (tile >= A.tiles) break;
             int pi = 0;
             if (A.nprob > 1 && tile >= A.p[1].tile0) pi = 1;
             if (A.nprob > 2 && tile >= A.p[2].tile0) pi = 2;
             if (A.nprob > 3 && tile >= A.p[3].tile0) pi = 3;
             const DoProb P = prob(pi);
+            const int m0t = (tile - P.tile0) * TM;
+            if (P.live) {
+                const int lim = max(1, *P.live);
+                const int last = min(m0t + TM, (int)P.M) - 1;
+                const int r0 = div_small(m0t, P.hw, P.r_hw), r1 = div_small(last, P.hw, P.r_hw);
+                const int j0 = r0 - div_small(r0, P.n_l, P.r_nl) * P.n_l, j1 = r1 - div_small(r1, P.n_l, P.r_nl) * P.n_l;
+                if (j0 >= lim && j1 >= lim && j0 <= j1) continue;
+            }
             L.pi = pi;
-            L.m0 = (tile - P.tile0) * TM;
+            L.m0 = m0t;
             L.x = reinterpret_cast<const char *>(P.x) + (long long)L.m0 * K * ES;
             const int rows = (int)P.M - L.m0;                 // >= 1: the tile exists
             L.x_bytes = (unsigned)((rows < TM ? rows : TM) * K * ES);
             L.w = reinterpret_cast<const char *>(P.wd) + (long long)pos * CM * K * ES;
+            break;
         }
         return L;
     };
@@ -219,7 +231,8 @@ deconv_out_kernel(const DoArgs A) {
     const float *tab = lds_wo + h * A.cp + col;
     const int cp2 = 2 * A.cp;
     for (;;) {
-        const Loc nxt = locate(u + grid);
+        int u_nx = u + grid;
+        const Loc nxt = locate(u_nx);
         if (cur.pi != tab_pi) {                       // first unit / the block crossed into the next RoI level
             const DoProb P = prob(cur.pi);
             __builtin_amdgcn_s_barrier();             // nobody reads the old tables any more
@@ -298,7 +311,7 @@ deconv_out_kernel(const DoArgs A) {
         }
         if (nxt.pi < 0) break;
         cur = nxt;
-        u += grid;
+        u = u_nx;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last chunk's look-ahead loads were empty, but are counted)
 }
@@ -350,7 +363,8 @@ static int deconv_out_entry(const ml_deconv_out_problem *probs, int32_t nprob, i
                    i, (long long)q.M, q.hw, q.w, q.rois_per_image);
         ML_REQUIRE((long long)(TM + 256) * K * es < (1ll << 31), "deconv2x2_out1x1: K too large");
         DoProb &P = A.p[i];
-        P.x = q.x; P.wd = q.wd; P.bd = q.bd; P.wo = q.wo_table; P.bo = q.bo; P.out = q.out;
+        P.x = q.x; P.wd = q.wd; P.bd = q.bd; P.wo = q.wo_table; P.bo = q.bo; P.out = q.out; P.live = q.live;
+        if (q.live) ML_REQUIRE((long long)q.hw * q.rois_per_image >= TM, "deconv2x2_out1x1: `live` needs at least one tile per image");
         P.M = q.M; P.hw = q.hw; P.w = q.w; P.n_l = q.rois_per_image; P.tile0 = tiles;
         P.r_hw = 1.f / (float)q.hw; P.r_w = 1.f / (float)q.w; P.r_nl = 1.f / (float)q.rois_per_image;
         P.img_stride = q.out_image_stride; P.base = q.out_base;

@@ -733,10 +733,13 @@ roi_crop_resize_kernel(const T *__restrict__ fmap, const float *__restrict__ row
                        const int *__restrict__ level_slots, const int *__restrict__ level_counts,
                        T *__restrict__ roi_fmaps, float *__restrict__ roi_boxes, int Hf, int Wf, int CV, int cap,
                        int L, int level, int n_l, int ch, int cw, float img_h, float img_w, int box_off,
-                       int box_rows) {
+                       int box_rows, const int *__restrict__ live) {
     constexpr int W = 16 / (int)sizeof(T);            // elements per 16-byte access
     const int j = blockIdx.x % n_l;
     const int b = blockIdx.x / n_l;
+    // fixed-capacity launch (n_l = cap, no host read of the RoI counts): only the first max(1, *live) slots of a level
+    // exist in the molded tensor (MoldBatch, misc.py:235-236); the others are never read by anyone
+    if (live && j >= max(1, *live)) return;
     const int cnt = level_counts[b * L + level];
     const int C = CV * W;
     T *dst = roi_fmaps + ((long long)b * n_l + j) * ch * cw * C;
@@ -890,7 +893,7 @@ template <class T>
 static int roi_crop_launch(const T *fmap, const float *rows, int32_t row_stride, int32_t row_off, const int32_t *level_slots,
                            const int32_t *level_counts, T *roi_fmaps, float *roi_boxes, int32_t B, int32_t Hf, int32_t Wf,
                            int32_t C, int32_t cap, int32_t L, int32_t level, int32_t n_l, int32_t ch, int32_t cw, float img_h,
-                           float img_w, int32_t box_off, int32_t box_rows, void *stream) {
+                           float img_w, int32_t box_off, int32_t box_rows, const int32_t *live, void *stream) {
     constexpr int W = 16 / (int)sizeof(T);
     ML_REQUIRE(fmap && rows && level_slots && level_counts && roi_fmaps && roi_boxes, "roi_crop: null pointer");
     ML_REQUIRE(row_off >= 0 && row_off + 6 <= row_stride, "roi_crop: rows must hold 6 columns from row_off");
@@ -899,7 +902,7 @@ static int roi_crop_launch(const T *fmap, const float *rows, int32_t row_stride,
     ML_REQUIRE(ml_aligned16(fmap) && ml_aligned16(roi_fmaps), "roi_crop: 16-byte alignment");
     hipLaunchKernelGGL(roi_crop_resize_kernel<T>, dim3((unsigned)(B * n_l)), dim3(256), 0, (hipStream_t)stream, fmap, rows,
                        row_stride, row_off, level_slots, level_counts, roi_fmaps, roi_boxes, Hf, Wf, C / W, cap, L, level, n_l, ch, cw, img_h,
-                       img_w, box_off, box_rows);
+                       img_w, box_off, box_rows, live);
     ML_CHECK_LAUNCH("roi_crop");
     return ML_OK;
 }
@@ -909,17 +912,63 @@ extern "C" int ml_roi_crop_resize_f32(const float *fmap, const float *rows, int3
                                       const int32_t *level_counts, float *roi_fmaps, float *roi_boxes, int32_t B,
                                       int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L, int32_t level,
                                       int32_t n_l, int32_t ch, int32_t cw, float img_h, float img_w, int32_t box_off,
-                                      int32_t box_rows, void *stream) {
+                                      int32_t box_rows, const int32_t *live, void *stream) {
     return roi_crop_launch<float>(fmap, rows, row_stride, row_off, level_slots, level_counts, roi_fmaps, roi_boxes, B, Hf, Wf, C,
-                                  cap, L, level, n_l, ch, cw, img_h, img_w, box_off, box_rows, stream);
+                                  cap, L, level, n_l, ch, cw, img_h, img_w, box_off, box_rows, live, stream);
 }
 
 extern "C" int ml_roi_crop_resize_f16(const void *fmap, const float *rows, int32_t row_stride, int32_t row_off,
                                       const int32_t *level_slots, const int32_t *level_counts, void *roi_fmaps,
                                       float *roi_boxes, int32_t B, int32_t Hf, int32_t Wf, int32_t C, int32_t cap, int32_t L,
                                       int32_t level, int32_t n_l, int32_t ch, int32_t cw, float img_h, float img_w,
-                                      int32_t box_off, int32_t box_rows, void *stream) {
+                                      int32_t box_off, int32_t box_rows, const int32_t *live, void *stream) {
     return roi_crop_launch<_Float16>(reinterpret_cast<const _Float16 *>(fmap), rows, row_stride, row_off, level_slots,
                                      level_counts, reinterpret_cast<_Float16 *>(roi_fmaps), roi_boxes, B, Hf, Wf, C, cap, L,
-                                     level, n_l, ch, cw, img_h, img_w, box_off, box_rows, stream);
+                                     level, n_l, ch, cw, img_h, img_w, box_off, box_rows, live, stream);
+}
+
+// ------------------------------------------------------------------ MoldBatch of a fixed-capacity stage 2
+// The forward without a host read keeps every RoI level at capacity: src [B, L*cap, E] (level l's RoIs at rows
+// l*cap ..).  Once the host knows the per-level maxima n_l (ONE read, after the whole forward has been enqueued) this
+// copies rows [l*cap, l*cap + n_l) of every image next to each other: dst [B, sum n_l, E] -- the reference's
+// Concatenate(axis=1) of the molded levels (engine/layers/instance.py:222-225).  E % 4 == 0: 16 bytes per lane.
+namespace {
+struct MoldArgs { int n_l[8], dst_off[8], L, cap, total; };
+__global__ void __launch_bounds__(256) mold_levels_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int E4, MoldArgs A,
+                                                           long long work) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= work) return;
+    const int e = (int)(idx % E4);
+    long long r = idx / E4;
+    const int row = (int)(r % A.total);
+    const int b = (int)(r / A.total);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < A.L && row >= A.dst_off[k]) l = k;
+    const int j = row - A.dst_off[l];
+    dst[((long long)b * A.total + row) * E4 + e] = src[((long long)b * A.L * A.cap + (long long)l * A.cap + j) * E4 + e];
+}
+}  // namespace
+
+extern "C" int ml_mold_levels_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
+                                  const int32_t *n_l, void *stream) {
+    ML_REQUIRE(src && dst && n_l && B > 0 && L >= 1 && L <= 8 && cap > 0 && E > 0 && E % 4 == 0,
+               "mold_levels: bad arguments (1..8 levels, E %% 4 == 0)");
+    ML_REQUIRE(ml_aligned16(src) && ml_aligned16(dst), "mold_levels: 16-byte alignment");
+    MoldArgs A;
+    A.L = L; A.cap = cap; A.total = 0;
+    for (int l = 0; l < 8; ++l) { A.n_l[l] = 0; A.dst_off[l] = 0; }
+    for (int l = 0; l < L; ++l) {
+        ML_REQUIRE(n_l[l] >= 1 && n_l[l] <= cap, "mold_levels: level %d keeps %d of %d slots", l, n_l[l], cap);
+        A.n_l[l] = n_l[l];
+        A.dst_off[l] = A.total;
+        A.total += n_l[l];
+    }
+    ML_REQUIRE(E / 4 < (1ll << 31), "mold_levels: rows too long");
+    const long long work = (long long)B * A.total * (E / 4);
+    hipLaunchKernelGGL(mold_levels_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), (int)(E / 4), A, work);
+    ML_CHECK_LAUNCH("mold_levels");
+    return ML_OK;
 }

@@ -330,7 +330,12 @@ struct GnProb {
     long long L, slice;
     int NG, S, C, G, relu, out_cs, out_co, onepass_vpt;   // onepass_vpt: 0 = two-pass, else float4 per thread
     float eps;
+    const int *live;          // fixed-capacity RoI batches: sample n is live iff n % live_period < max(1, *live)
+    int live_period;
 };
+__device__ __forceinline__ bool gn_dead(const GnProb &P, int ng) {
+    return P.live && ((ng / P.G) % P.live_period) >= max(1, *P.live);
+}
 struct GnMulti {
     int n;
     int start[ML_GN_MAX_PROBLEMS + 1];
@@ -344,6 +349,7 @@ gn_multi_stats_kernel(const GnMulti A) {
     while (pi + 1 < A.n && (int)blockIdx.x >= A.start[pi + 1]) ++pi;
     const GnProb &P = A.p[pi];
     const int id = blockIdx.x - A.start[pi];
+    if (gn_dead(P, id / P.S)) return;
     gn_stats_body<T>(reinterpret_cast<const T *>(P.x), P.ws, P.L, P.slice, P.S, id / P.S, id % P.S);
 }
 
@@ -356,6 +362,7 @@ gn_multi_apply_kernel(const GnMulti A) {
     const int id = blockIdx.x - A.start[pi];
     const T *x = reinterpret_cast<const T *>(P.x);
     T *y = reinterpret_cast<T *>(P.y);
+    if (gn_dead(P, P.onepass_vpt == 0 ? id / P.S : id)) return;          // (block-uniform)
     if (P.onepass_vpt == 0) {
         gn_apply_body<T>(x, y, P.gamma, P.beta, P.ws, P.L, P.slice, P.S, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co,
                          id / P.S, id % P.S);
@@ -407,6 +414,8 @@ static int gn_multi(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t
         P.x = d.x; P.y = d.y; P.gamma = d.gamma; P.beta = d.beta;
         P.L = L; P.NG = d.N * d.G; P.C = d.C; P.G = d.G; P.relu = d.relu; P.out_cs = d.out_cstride; P.out_co = d.out_coff;
         P.eps = d.eps;
+        P.live = d.live; P.live_period = d.live_period;
+        if (d.live) ML_REQUIRE(d.live_period >= 1 && d.N % d.live_period == 0, "groupnorm_multi: live_period must divide N");
         P.ws = nullptr; P.S = 1; P.slice = L; P.onepass_vpt = 0;
         if (L <= GN_ONEPASS_MAX) {
             const int vn = (int)((L + W - 1) / W);

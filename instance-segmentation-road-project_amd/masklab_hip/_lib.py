@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
 LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
 
-ABI_VERSION = 4          # ML_ABI_VERSION of include/masklab_hip.h
+ABI_VERSION = 5          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("group_cin_step", C.c_int32), ("shuffle2x2", C.c_int32),
         ("tile", C.c_int32), ("math", C.c_int32), ("out_f16", C.c_int32),
         ("out_bstride", C.c_int64),
+        ("live", C.c_void_p), ("live_period", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -40,7 +41,8 @@ class GnDesc(C.Structure):
     """Mirror of `ml_gn_desc` (include/masklab_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("HWC", C.c_int64), ("N", C.c_int32), ("C", C.c_int32), ("G", C.c_int32), ("relu", C.c_int32),
-                ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
+                ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32),
+                ("live", C.c_void_p), ("live_period", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DeconvOutProblem(C.Structure):
@@ -48,7 +50,7 @@ class DeconvOutProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p), ("wo_table", C.c_void_p),
                 ("bo", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("hw", C.c_int32), ("w", C.c_int32),
                 ("rois_per_image", C.c_int32), ("reserved0", C.c_int32), ("out_image_stride", C.c_int64),
-                ("out_base", C.c_int64)]
+                ("out_base", C.c_int64), ("live", C.c_void_p)]
 
 
 GN_MAX_PROBLEMS = 8
@@ -77,7 +79,7 @@ SIGNATURES = {
     "ml_dwconv3x3_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_global_mean_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "ml_groupnorm_chunk_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
-    "ml_roi_crop_resize_f16": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp]),
+    "ml_roi_crop_resize_f16": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp, _vp]),
     "ml_deconv2x2_out1x1_f16": (C.c_int, [C.POINTER(DeconvOutProblem), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ml_dwconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 15 + [_vp]),
     "ml_maxpool3x3s2_f32": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
@@ -93,7 +95,8 @@ SIGNATURES = {
     "ml_detection_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "ml_detection_proposal_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "ml_mask_distribute_i32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
-    "ml_roi_crop_resize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp]),
+    "ml_roi_crop_resize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp, _vp]),
+    "ml_mold_levels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, C.POINTER(C.c_int32), _vp]),
     "ml_add_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_fill_f32": (C.c_int, [_vp, _f32, _i64, _vp]),
     "ml_resize_image_ac": (C.c_int, [_vp, _i32, _vp, _vp, _f32] + [_i32] * 6 + [_vp]),

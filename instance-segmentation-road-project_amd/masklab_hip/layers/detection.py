@@ -105,7 +105,7 @@ class _TowerMixin:
         return x
 
     @staticmethod
-    def _run_towers_multi(blocks, xs):
+    def _run_towers_multi(blocks, xs, lives=None):
         """Depth-major execution of several un-shared towers (one per pyramid level / RoI level):
         the conv of depth i runs for ALL towers in one multi-problem launch, so the few-tile
         problems of the coarse levels ride along with the fine level instead of each being a
@@ -115,14 +115,18 @@ class _TowerMixin:
                                               isinstance(b[2 * i + 1], GroupNormalization)
                                               for i in range(len(b) // 2)) for b in blocks)
         if not plain or len({len(b) for b in blocks}) != 1:
+            if lives is not None:
+                raise NotImplementedError("fixed-capacity RoI batches: plain [Conv2D, GroupNormalization] towers only")
             return [_TowerMixin._run_tower(b, x) for b, x in zip(blocks, xs)]
         xs = list(xs)
+        lives = lives if lives is not None else [None] * len(xs)
         for i in range(len(blocks[0]) // 2):
             convs = [b[2 * i] for b in blocks]
             xs = ops.conv2d_multi([dict(x=x, dc=c.dev, stride=c.strides[0], padding=c.padding,
-                                        dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation])
-                                   for c, x in zip(convs, xs)])
-            xs = GroupNormalization.call_multi([b[2 * i + 1] for b in blocks], xs, inplace=True)
+                                        dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation], live=lv)
+                                   for c, x, lv in zip(convs, xs, lives)])
+            xs = GroupNormalization.call_multi([b[2 * i + 1] for b in blocks], xs, inplace=True,
+                                               lives=None if all(lv is None for lv in lives) else lives)
         return xs
 
     @staticmethod

@@ -61,6 +61,21 @@ class PyramidRoiAlign(Layer):
             off += n_l[level]
         return roi_fmaps, roi_boxes
 
+    def crop_capacity(self, fmap_outputs, rows, image_hw, slots, lcounts, lmax):
+        """The same crops with NO host read: every level is launched at capacity (n_l = cap RoI slots per image) and the
+        kernels skip the slots past the level's maximum, which they read from `lmax` on the device.
+        -> (roi_fmaps per level [B,cap,ch,cw,C], roi_boxes_cap [B,L*cap,6], lives = [(lmax[l:l+1], cap)])."""
+        B, cap = rows.shape[0], rows.shape[1]
+        L = len(fmap_outputs)
+        roi_boxes = torch.empty((B, L * cap, 6), dtype=torch.float32, device=rows.device)
+        roi_fmaps, lives = [], []
+        for level, fmap in enumerate(fmap_outputs):
+            live = lmax[level:level + 1]
+            roi_fmaps.append(ops.roi_crop_resize(fmap, rows, slots, lcounts, level, cap, tuple(self.crop_size), image_hw,
+                                                 roi_boxes, level * cap, live=live))
+            lives.append((live, cap))
+        return roi_fmaps, roi_boxes, lives
+
     def crop_levels(self, fmap_outputs, rows, image_hw, has_k, base_size=1.0):
         """rows: [B,cap,6] proposals (has_k=False) or [B,cap,7] dist_boxes (has_k=True)."""
         slots, lcounts, lmax = self.distribute(len(fmap_outputs), rows, has_k, base_size)
@@ -135,7 +150,7 @@ class MaskSubNet(Layer, _TowerMixin):
             table, bo, _ = packing.pack_out1x1_table(k, b)
             self._tail_tables.append((torch.from_numpy(table).to(device), torch.from_numpy(bo).to(device)))
 
-    def _fused_tail(self, blocks, xs, shapes, roi_masks, per_roi):
+    def _fused_tail(self, blocks, xs, shapes, roi_masks, per_roi, lives=None):
         """Conv2DTranspose + ReLU -> Conv2D 1x1 + sigmoid of every level in one launch, written straight into
         `roi_masks` (csrc/deconv_out.hip); False when the configuration is outside that kernel's shapes."""
         from .. import _lib
@@ -149,13 +164,22 @@ class MaskSubNet(Layer, _TowerMixin):
         for i, ((_, n), b, x) in enumerate(zip(shapes, blocks, xs)):
             table, bo = self._tail_tables[i]
             problems.append(dict(x=x.contiguous(), dc=b[-2].dev, wo_table=table, bo=bo, out=roi_masks,
-                                 out_base=off * per_roi, rois_per_image=n))
+                                 out_base=off * per_roi, rois_per_image=n,
+                                 live=None if lives is None else lives[i][0]))
             off += n
         ops.deconv2x2_out1x1_multi(problems, self.num_classes, _lib.ACT_BY_NAME[blocks[0][-2].activation],
                                    _lib.ACT_BY_NAME[blocks[0][-1].activation])
         return True
 
-    def call(self, inputs, **kwargs):
+    def capacity_supported(self, crop_size):
+        """True when the whole head runs in the fixed-capacity form (plain towers + the fused tail kernel)."""
+        plain = all(len(b) >= 2 and all(type(l).__name__ in ("Conv2D", "GroupNormalization") for l in b[:-2]) for b in self.blocks)
+        return plain and getattr(self, "_tail_tables", None) is not None and crop_size[0] * crop_size[1] >= 2
+
+    def call(self, inputs, lives=None, **kwargs):
+        """lives (fixed-capacity form, PyramidRoiAlign.crop_capacity): per level (device int32 [1], cap) -- RoI slots past
+        max(1, live) of an image do not exist; the result is then [B, L*cap, 2h, 2w, classes] with level l's RoIs at
+        rows l*cap .. (molded by ops.mold_levels once the host knows the maxima)."""
         if not isinstance(inputs, list):
             inputs = [inputs]
         from .. import _lib
@@ -163,14 +187,16 @@ class MaskSubNet(Layer, _TowerMixin):
         shapes = [(h.shape[0], h.shape[1]) for h in inputs]
         # fold rois into the batch (:211-213); all levels advance together (multi-problem launches)
         xs = [h.reshape((h.shape[0] * h.shape[1],) + tuple(h.shape[2:])) for h in inputs]
-        xs = self._run_towers_multi([b[:-2] for b in blocks], xs)
+        xs = self._run_towers_multi([b[:-2] for b in blocks], xs, lives=lives)
         if all(n > 0 for _, n in shapes):
             B = shapes[0][0]
             oh, ow, ncls = 2 * int(xs[0].shape[1]), 2 * int(xs[0].shape[2]), self.num_classes
             total = sum(n for _, n in shapes)
             roi_masks = torch.empty((B, total, oh, ow, ncls), dtype=torch.float32, device=xs[0].device)
-            if self._fused_tail(blocks, xs, shapes, roi_masks, oh * ow * ncls):
+            if self._fused_tail(blocks, xs, shapes, roi_masks, oh * ow * ncls, lives=lives):
                 return roi_masks
+        if lives is not None:
+            raise NotImplementedError("MaskSubNet: the fixed-capacity form needs the fused tail kernel")
         if xs[0].dtype == torch.float16:          # (the pixel-shuffle epilogue of the unfused pair is fp32 only)
             xs = [ops.cast_h2f(x) for x in xs]
         xs = ops.conv2d_multi([dict(x=x, dc=b[-2].dev, act=_lib.ACT_BY_NAME[b[-2].activation])

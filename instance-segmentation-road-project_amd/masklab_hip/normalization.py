@@ -68,11 +68,14 @@ class GroupNormalization(Layer):
                                    out=inputs if inplace else None)
 
     @staticmethod
-    def call_multi(layers, inputs, inplace=False):
+    def call_multi(layers, inputs, inplace=False, lives=None):
         """The same layers applied to their own inputs in ONE launch pair (the un-shared towers normalise five pyramid
-        levels at every depth, reference engine/layers/detection.py:124,194): results identical to calling each."""
+        levels at every depth, reference engine/layers/detection.py:124,194): results identical to calling each.
+        lives: per input None or (device int32 [1], slots per image) -- a fixed-capacity RoI batch whose samples past
+        max(1, live) per image do not exist and are skipped."""
         probs = []
-        for layer, x in zip(layers, inputs):
+        lives = lives if lives is not None else [None] * len(inputs)
+        for layer, x, live in zip(layers, inputs, lives):
             if not layer.built:
                 layer.build(tuple(x.shape))
             if (layer.scale and layer.gamma is None) or (layer.center and layer.beta is None):
@@ -80,9 +83,11 @@ class GroupNormalization(Layer):
             hwc = x.numel() // x.shape[0]
             vw = 16 // x.element_size()                             # elements per 16-byte access: 4 floats / 8 halves
             if (hwc // layer.groups) % vw or x.shape[-1] % vw:      # the multi launch takes vectorisable problems only
+                if any(lv is not None for lv in lives):
+                    raise NotImplementedError("GroupNormalization: fixed-capacity batches need vectorisable chunks")
                 return [l(x_, inplace=inplace) for l, x_ in zip(layers, inputs)]
             probs.append(dict(x=x, gamma=layer.gamma, beta=layer.beta, groups=layer.groups, eps=layer.epsilon,
-                              out=x if inplace else None))
+                              out=x if inplace else None, live=live))
         return ops.groupnorm_chunk_multi(probs)
 
     def get_config(self):

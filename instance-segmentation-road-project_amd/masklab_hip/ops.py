@@ -132,7 +132,7 @@ class DeviceConv:
 
 
 def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, residual=None, out=None,
-               out_coff=0, in_coff=0, out_view=None, out_dtype=None):
+               out_coff=0, in_coff=0, out_view=None, out_dtype=None, live=None):
     """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args).
     A float16 `x` selects the fp16-storage kernels (ML_MATH_F16S: half weights, half residual); the output is half
     unless the destination says otherwise (`out` / `out_view` tensor of dtype float32, out_dtype=torch.float32, or a
@@ -199,6 +199,10 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
+    if live is not None:               # (device int32 tensor [1], slots per image): a fixed-capacity RoI batch
+        lv, period = live
+        _require_dev(lv, "live")
+        d.live, d.live_period = lv.data_ptr(), int(period)
     if half_in:
         d.math, d.out_f16 = 2, int(odt == torch.float16)          # ML_MATH_F16S
     else:
@@ -314,6 +318,8 @@ def deconv2x2_out1x1_multi(problems, ncls, act_mid, act_out):
         d.wo_table, d.bo, d.out = pr["wo_table"].data_ptr(), pr["bo"].data_ptr(), out.data_ptr()
         d.M, d.hw, d.w, d.rois_per_image, d.reserved0 = R * h * w, h * w, w, n_l, 0
         d.out_image_stride, d.out_base = out.stride(0), int(pr["out_base"])
+        if pr.get("live") is not None:
+            d.live = pr["live"].data_ptr()
         last = (R // n_l - 1) * out.stride(0) + int(pr["out_base"]) + n_l * 4 * h * w * ncls
         if R % n_l or last > out.numel():
             raise ValueError("deconv2x2_out1x1: the RoI block does not fit the output tensor")
@@ -495,6 +501,9 @@ def groupnorm_chunk_multi(problems):
             raise ValueError("groupnorm_multi: every x / out of one launch must share the dtype")
         d.relu, d.out_cstride, d.out_coff, d.eps = int(pr.get("relu", False)), out_cs, out_coff, float(pr.get("eps", 1e-5))
         d.dtype = int(x.dtype == torch.float16)
+        if pr.get("live") is not None:
+            lv, period = pr["live"]
+            d.live, d.live_period = lv.data_ptr(), int(period)
         ws_bytes += (int(lib.ml_groupnorm_workspace_bytes(N, pr["groups"])) + 255) // 256 * 256
         nbytes += 2 * x.element_size() * x.numel()
         outs.append(out)
@@ -598,8 +607,9 @@ def mask_distribute(rows, max_k, base_size, has_k=False, want_k=False):
     return slots, lcounts, lmax, kvals
 
 
-def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, roi_boxes, box_off):
-    """rows [B,cap,6] (cx,cy,w,h,cls,conf) or [B,cap,7] dist_boxes (k first)."""
+def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, roi_boxes, box_off, live=None):
+    """rows [B,cap,6] (cx,cy,w,h,cls,conf) or [B,cap,7] dist_boxes (k first).  live: device int32 [1] = the level's
+    RoI maximum when the launch runs at capacity (n_l = cap): slots past max(1, live) are not written."""
     lib = _lib.load()
     _require_dev(fmap, "fmap")
     B, Hf, Wf, Cc = fmap.shape
@@ -611,7 +621,26 @@ def roi_crop_resize(fmap, rows, slots, lcounts, level, n_l, crop_size, img_hw, r
     fn = lib.ml_roi_crop_resize_f16 if fmap.dtype == torch.float16 else lib.ml_roi_crop_resize_f32
     _lib.check(fn(_ptr(fmap), _ptr(rows), rs, roff, _ptr(slots), _ptr(lcounts), _ptr(out),
                   _ptr(roi_boxes), B, Hf, Wf, Cc, cap, L, level, n_l, ch, cw,
-                  float(img_hw[0]), float(img_hw[1]), box_off, roi_boxes.shape[1], _stream()), "ml_roi_crop_resize")
+                  float(img_hw[0]), float(img_hw[1]), box_off, roi_boxes.shape[1], _ptr(live), _stream()), "ml_roi_crop_resize")
+    return out
+
+
+def mold_levels(src, n_l, cap):
+    """ml_mold_levels_f32: src [B, L*cap, ...] (level l's RoIs at rows l*cap ..) -> [B, sum(n_l), ...] with the first n_l[l]
+    rows of every level next to each other; n_l: host ints."""
+    lib = _lib.load()
+    _require_dev(src, "src")
+    if src.dtype != torch.float32:
+        raise RuntimeError("mold_levels: float32 tensor expected")
+    B, L = src.shape[0], len(n_l)
+    if src.shape[1] != L * cap:
+        raise ValueError(f"mold_levels: {src.shape[1]} rows per image, expected {L} x {cap}")
+    E = int(np.prod(src.shape[2:]))
+    if E % 4:                                      # [B, L*cap, 6] boxes: tiny, plain slicing (data movement only)
+        return torch.cat([src[:, l * cap:l * cap + n] for l, n in enumerate(n_l)], dim=1).contiguous()
+    out = torch.empty((B, int(sum(n_l))) + tuple(src.shape[2:]), dtype=torch.float32, device=src.device)
+    arr = (C.c_int32 * L)(*[int(n) for n in n_l])
+    _lib.check(lib.ml_mold_levels_f32(_ptr(src), _ptr(out), B, L, int(cap), E, arr, _stream()), "ml_mold_levels_f32")
     return out
 
 

@@ -133,6 +133,11 @@ class InferenceModel(K.Layer):
         # hipGraph capture they are always worth it (the branches replay without host work: 1.94 ms).
         self.use_side_stream = "auto"
         self._side_stream = None
+        # Stage 2 without a host read ("dynamic shapes without host sync"): RoI crops + mask head launched at
+        # capacity, the kernels reading the per-level RoI maxima from device memory; the molded shapes are produced when
+        # the outputs are handed over (ONE read, after the whole forward is enqueued).  True / False / "auto" = with
+        # hipGraph replay (the whole forward is then ONE graph), where nothing but that read remains for the host.
+        self.device_counts = "auto"
         self._build_shapes()
 
     # ---- structure
@@ -286,7 +291,7 @@ class InferenceModel(K.Layer):
         if side is not None:
             st["side"] = side
             st["keepalive"] = by_name            # backbone taps the side stream still reads
-            if torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing() and not getattr(self, "_capturing_whole", False):
                 self._join_side(st)              # a captured stage 1 must be self-contained
         elif self.semantic_networks is not None:
             # independent of the instance branch and enqueued BEFORE the host reads the RoI counts, so the
@@ -339,33 +344,85 @@ class InferenceModel(K.Layer):
             outputs.append(st["seg_pred"])
         return outputs
 
-    # ---- hipGraph replay of stage 1 (launch-bound small batches: serving one image at a time)
+    # ---- stage 2 at capacity: no host read inside the forward
+    MAX_CAPACITY_ROIS = 8192            # B x nms_max_output_size above which the capacity tensors are not worth their memory
+
+    def _capacity_wanted(self, images):
+        mode = getattr(self, "device_counts", "auto")
+        on = self._use_graphs if mode == "auto" else bool(mode)
+        if not on or self.instance_networks is None:
+            return False
+        pra, mask = self.instance_networks[2], self.instance_networks[3]
+        cap = int(self.detection_proposal.nms_max_output_size)
+        return (mask.capacity_supported(tuple(pra.crop_size)) and int(images.shape[0]) * cap <= self.MAX_CAPACITY_ROIS
+                and cap * pra.crop_size[0] * pra.crop_size[1] >= 128)
+
+    def _stage2_capacity(self, st):
+        """RoI crops + mask head with every level at capacity (reference engine/layers/instance.py:115-134,211-233 +
+        MoldBatch misc.py:231-286): kernels skip the RoI slots past the level maxima they read on the device.
+        -> the forward's RAW result: fixed-shape tensors + `lmax` (what `_mold` needs the host to read)."""
+        _, _, pyramid_roi_align, mask_subnet = self.instance_networks
+        roi_fmaps, boxes_cap, lives = pyramid_roi_align.crop_capacity(
+            st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"], st["lmax"])
+        masks_cap = mask_subnet(roi_fmaps, lives=lives)
+        self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"], boxes=st["boxes"],
+                                    payload=st["payload"])
+        self._join_side(st)
+        return dict(cls_pred=st["cls_pred"], loc_pred=st["loc_pred"], boxes_cap=boxes_cap, masks_cap=masks_cap,
+                    lmax=st["lmax"], cap=int(st["proposed"].shape[1]), seg_pred=st.get("seg_pred"))
+
+    def _mold(self, raw):
+        """The ONE host read of the forward (the per-level RoI maxima, L ints) and the molded outputs it sizes."""
+        from . import ops
+        n_l = [max(1, int(v)) for v in raw["lmax"].tolist()]
+        outputs = [raw["cls_pred"], raw["loc_pred"], ops.mold_levels(raw["boxes_cap"], n_l, raw["cap"]),
+                   ops.mold_levels(raw["masks_cap"], n_l, raw["cap"])]
+        if self.semantic_networks is not None:
+            outputs.append(raw["seg_pred"])
+        return outputs
+
+    # ---- hipGraph replay (launch-bound small batches: serving one image at a time)
     def enable_graphs(self, enabled=True):
-        """Capture stage 1 (~250 kernel launches) into a hipGraph per input shape and replay it: one
-        launch instead of hundreds, which is what a batch-1 forward is bound by.  The tensors stage 1
-        returns (cls_pred, loc_pred, seg_pred) are then graph-owned buffers, valid until the next call."""
+        """Capture the forward (~300 kernel launches) into a hipGraph per input shape and replay it: one launch instead
+        of hundreds, which is what a batch-1 forward is bound by.  With the fixed-capacity stage 2 (`device_counts`) the
+        WHOLE forward is one graph; otherwise stage 1 is (stage 2's shapes then depend on a host read).  The tensors
+        the graph returns are graph-owned buffers, valid until the next call (`outputs_graph_owned`)."""
         self._use_graphs = bool(enabled)
         if not enabled:
             self._graphs = {}
         return self
 
-    def _stage1_graphed(self, images):
+    @property
+    def outputs_graph_owned(self):
+        return bool(self._use_graphs)
+
+    def _stage1_graphed(self, images, whole=False):
         from . import ops
         # kernel arguments are baked into a capture: everything they are computed from is part of the key
         dp = self.detection_proposal
-        key = (tuple(images.shape), images.dtype, ops.CONV_MATH) + (
+        key = (tuple(images.shape), images.dtype, ops.CONV_MATH, bool(whole)) + (
             () if dp is None else (float(dp.min_confidence), float(dp.nms_iou_threshold), float(dp.post_iou_threshold),
                                    int(dp.nms_max_output_size)))
         entry = self._graphs.get(key)
         if entry is None:
             if ops.PROFILE is not None:
                 raise RuntimeError("graph capture cannot run under the per-launch profiling hook")
-            self._join_side(self._stage1(images))    # warm-up: fills the anchor / workspace caches, sets kernel attributes
+            # warm-up: fills the anchor / workspace caches, sets kernel attributes
+            if whole:
+                self._stage2_capacity(self._stage1(images))
+            else:
+                self._join_side(self._stage1(images))
             torch.cuda.synchronize(self.device)
             static_in = images.clone()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                st = self._stage1(static_in)
+            self._capturing_whole = bool(whole)          # (the side stream then joins at the end of stage 2)
+            try:
+                with torch.cuda.graph(graph):
+                    st = self._stage1(static_in)
+                    if whole:
+                        st = self._stage2_capacity(st)
+            finally:
+                self._capturing_whole = False
             entry = self._graphs[key] = (graph, static_in, st)
         graph, static_in, st = entry
         static_in.copy_(images)
@@ -380,7 +437,14 @@ class InferenceModel(K.Layer):
         images = images.to(self.device).contiguous()
         want_kept = kwargs.get("want_kept", False)
         from . import ops
-        if getattr(self, "_use_graphs", False) and not want_kept and ops.PROFILE is None:
+        graphs = getattr(self, "_use_graphs", False) and not want_kept and ops.PROFILE is None
+        if not want_kept and self._capacity_wanted(images):
+            # no host read inside the forward; with graphs the whole of it is one replay
+            raw = self._stage1_graphed(images, whole=True) if graphs else self._stage2_capacity(self._stage1(images))
+            if kwargs.get("defer", False):
+                return DeferredOutputs(self, raw)
+            return self._mold(raw)
+        if graphs:
             st = self._stage1_graphed(images)
         else:
             st = self._stage1(images, want_kept=want_kept)
@@ -389,8 +453,23 @@ class InferenceModel(K.Layer):
     def predict(self, images, **kwargs):
         """Keras `Model.predict`: numpy in, list of numpy out."""
         outs = self.call(images, **kwargs)
+        if isinstance(outs, DeferredOutputs):
+            outs = outs.materialize()
         torch.cuda.synchronize(self.device)
         return [o.cpu().numpy() for o in outs]
+
+
+class DeferredOutputs:
+    """What `InferenceModel(images, defer=True)` returns on the fixed-capacity path: the forward is fully enqueued and
+    NOTHING has been read by the host yet, so a caller that pipelines forwards (bench.py) never stalls; `materialize()`
+    does the one read (per-level RoI maxima) and returns the molded output list, shaped exactly like the reference's
+    (roi_boxes / roi_masks with N = sum of the level maxima, engine/layers/misc.py:231-286)."""
+
+    def __init__(self, model, raw):
+        self.model, self.raw = model, raw
+
+    def materialize(self):
+        return self.model._mold(self.raw)
 
 
 def construct_inference_network(configuration: ModelConfiguration, backbone_network, detection_networks=None,

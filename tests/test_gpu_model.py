@@ -184,7 +184,17 @@ def test_hipgraph_replay_equals_eager(bt):
     cfg, model, w = _build(bt, seed=5, hot_cls=True)
     rng = np.random.default_rng(7)
     imgs = [rng.integers(0, 256, (1, 128, 256, 3), dtype=np.uint8) for _ in range(3)]
+    host_read = [model.predict(im) for im in imgs]         # stage 2 sized by the host's read of the RoI counts
+    model.device_counts = True                             # the same launches the graph captures, issued eagerly
     eager = [model.predict(im) for im in imgs]
+    model.device_counts = "auto"
+    for a, b in zip(host_read, eager):
+        for name, x, y in zip(model.output_names, a, b):
+            assert x.shape == y.shape, name                # molded exactly like MoldBatch (reference misc.py:231-286)
+            if name == "roi_masks":                        # (a launch at capacity may cut its K sum elsewhere: fp32 rounding)
+                np.testing.assert_allclose(x, y, atol=1e-5, err_msg=name)
+            else:
+                np.testing.assert_array_equal(x, y, err_msg=name)
     model.enable_graphs(True)
     for rep in range(2):                                   # first pass captures, second only replays
         for im, want in zip(imgs, eager):
@@ -192,6 +202,7 @@ def test_hipgraph_replay_equals_eager(bt):
             for name, g, r in zip(model.output_names, got, want):
                 np.testing.assert_array_equal(g, r, err_msg=f"{name} (pass {rep})")
     assert len(model._graphs) == 1
+    assert next(iter(model._graphs))[3] is True        # the WHOLE forward is the graph (fixed-capacity stage 2, no host read)
     other = rng.integers(0, 256, (2, 128, 128, 3), dtype=np.uint8)     # a second shape gets its own graph
     model.enable_graphs(False)
     want = model.predict(other)
@@ -385,3 +396,29 @@ def test_batch_sharding_where_the_split_k_decision_differs():
     pr, rc, fm = OM.detection_iou_metric(prop.cpu().numpy(), full["proposed"].cpu().numpy())
     np.testing.assert_allclose(fm, 1.0, atol=1e-6)
     assert torch.equal(prop[..., 4].sort(dim=1).values, full["proposed"][..., 4].sort(dim=1).values)   # same class multiset
+
+
+@pytest.mark.parametrize("bt,shape,thr", [("mobilenet", (3, 128, 256, 3), 0.5), ("resnext50", (2, 192, 160, 3), 0.5),
+                                          ("mobilenet", (2, 128, 128, 3), 0.999)])
+def test_fixed_capacity_stage2_matches_oracle(bt, shape, thr):
+    """Stage 2 WITHOUT a host read (device_counts): RoI crops, mask-head convs / GroupNorms / fused tail launched for
+    all nms_max_output_size slots of every level, the kernels skipping slots past the per-level maxima they read on the
+    device; outputs molded afterwards.  Same result as the oracle (shapes = MoldBatch's dynamic N, indices exact),
+    including images without detections (thr 0.999: every level molds to 1 padded row) and deferred outputs."""
+    cfg, model, w = _build(bt, seed=5, hot_cls=True)
+    images = np.random.default_rng(shape[1] + shape[2]).integers(0, 256, shape, dtype=np.uint8)
+    if thr < 0.9:      # threshold in a score gap (see test_full_forward_with_detections)
+        cls_ref = O.inference_forward(cfg, w, images, literal_groups=False, with_instance=False, with_semantic=False)[0]
+        s = np.sort(cls_ref[(cls_ref > 0.45) & (cls_ref < 0.55)].astype(np.float64))
+        i = int(np.argmax(np.diff(s)))
+        thr = float(np.float32((s[i] + s[i + 1]) / 2))
+    cfg.detection.min_confidence = thr
+    model.detection_proposal.min_confidence = thr
+    model.device_counts = True
+    got = model.predict(images)
+    want = O.inference_forward(cfg, w, images, literal_groups=False)
+    _check(model, got, want)
+    deferred = model(torch.from_numpy(images).cuda(), defer=True)
+    assert type(deferred).__name__ == "DeferredOutputs"
+    for g, r in zip(deferred.materialize(), got):
+        np.testing.assert_array_equal(g.cpu().numpy(), r)

@@ -20,7 +20,7 @@ def test_shared_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in masklab_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.ml_version() == _lib.ABI_VERSION == 4
+    assert lib.ml_version() == _lib.ABI_VERSION == 5
     assert lib.ml_conv2d_workspace_bytes() > 0 and lib.ml_groupnorm_workspace_bytes(8, 16) > 0
     assert lib.ml_detection_workspace_bytes(8, 327360, 5, 100) > 8 * 5 * 327360 * 24
 
@@ -28,8 +28,12 @@ def test_shared_library_exports_every_header_symbol():
 def test_conv_desc_struct_matches_header_layout():
     import ctypes
     from masklab_hip import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 28 * 4 + 8       # 5 pointers, 28 int32, 1 int64
+    # 5 pointers, 28 int32, 1 int64, then (ABI 5) the `live` pointer + 2 int32
+    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 28 * 4 + 8 + 8 + 2 * 4
     assert _lib.ConvDesc.out_bstride.offset == 152 and _lib.ConvDesc.math.offset == 144
+    assert _lib.ConvDesc.live.offset == 160 and _lib.ConvDesc.live_period.offset == 168
+    assert ctypes.sizeof(_lib.GnDesc) == 4 * 8 + 8 + 8 * 4 + 8 + 2 * 4 and _lib.GnDesc.live.offset == 72
+    assert ctypes.sizeof(_lib.DeconvOutProblem) == 6 * 8 + 8 + 4 * 4 + 2 * 8 + 8 and _lib.DeconvOutProblem.live.offset == 88
 
 
 def test_product_fails_loudly_without_gpu_tensors():
