@@ -80,7 +80,7 @@ typedef struct ml_conv2d_desc {
     int32_t act;            /* ML_ACT_*                                                       */
     int32_t group_cin_step; /* grouped 3x3: input-channel offset per 32-wide N block; else 0  */
     int32_t shuffle2x2;     /* 1: Conv2DTranspose epilogue, column = (a*2+b)*cout_real + o    */
-    int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32, 4 = pipelined 1x1 (128x128) */
+    int32_t tile;           /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 128x32, 4 = pipelined 1x1 (128x128), 5 = half 1x1 on 256x256 tiles */
     int32_t math;           /* ML_MATH_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products);
                                ML_MATH_F16: operands rounded to fp16 on their way into LDS,
                                v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5);
@@ -124,8 +124,10 @@ int ml_conv2d_ntile(int32_t cout, int32_t tile);
  * problems: launches too small to fill the chip with 128-wide tiles run on narrower ones (bit-identical results:
  * same k-ordered chains, split-K cut at the same k).  For reporting only; 0 on bad arguments. */
 int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace);
-/* 1 when ml_conv2d_multi_f32 runs this single problem on the persistent, tile-pipelined 1x1 kernel
- * (conv1x1_pipe.hip: the short-K bottleneck convs of engine/backbone/ResNext.py:199-231), else 0. */
+/* Which persistent 1x1 kernel ml_conv2d_multi_f32 runs this single problem on: 1 = the tile-pipelined 128 x 128 kernel
+ * (conv1x1_pipe.hip: the short-K bottleneck convs of engine/backbone/ResNext.py:199-231; fp32 or half tensors),
+ * 2 = the 256 x 256-tile kernel for half tensors with K >= 256 (conv1x1_h256.hip: the ResNeXt-101 stage 2-4 convs of
+ * BASELINE configs[4]), 0 = neither (the generic implicit-GEMM kernel).  `tile` = 4 / 5 force 1 / 2 where they apply. */
 int ml_conv2d_uses_pipe(const ml_conv2d_desc *d);
 
 /* ResNeXt grouped 3x3 (reference engine/backbone/ResNext.py:212-219: DepthwiseConv2D(depth_multiplier=c)

@@ -1,0 +1,348 @@
+// 1x1 convolution on IEEE-half tensors as a 256 x 256-tile GEMM:  out[M, N] = act(in[M, K] * wgt[N, K]^T + bias + residual)
+// for the K >= 256 bottleneck convs of an fp16-STORAGE ResNeXt body (BASELINE configs[4]: ResNeXt-101 stage 3 is 46
+// launches of M = 102 400, K / N = 1024 / 512 and 512 / 1024; thirdparty/classification_models/models/resnext.py:62-135).
+//
+// Why a second kernel beside conv1x1_pipe.hip: on half tensors a 128 x 128 tile with 64 x 64 per wave stages 32 KB for
+// 16 MFMAs per wave and chunk -- 8 LDS-direct loads (each ~60-100 cycles of issue) beside 512 cycles of matrix work, and
+// 64 B/clk/CU through the L2 -> LDS path, which is all that path has.  Here a block is 8 waves (2 per SIMD) on a
+// 256 x 256 tile, 128 x 64 per wave: the same 8 loads per wave and chunk feed 32 MFMAs, every staged byte is used for
+// twice the MACs, and the LDS-read traffic per MAC drops by a quarter.
+//   * K chunk = 64 halves = 128 bytes per row (full cache lines; XOR-swizzled 16-byte groups as in the other kernels),
+//     two 64 KB staging buffers (A 256 rows + B 256 rows), filled by `buffer_load_dwordx4 ... lds`;
+//   * the chunk stream crosses tile boundaries: a block is PERSISTENT, walks its tiles, and the first chunk of the next
+//     tile is in flight during the epilogue of the current one;
+//   * all N tiles of an M panel run at the same time on ONE XCD (blocks with equal blockIdx & 7), so the panel comes from
+//     beyond L2 once;
+//   * epilogue: accumulators -> wave-private LDS scratch (16 rows x 32 columns at a time) -> rows of 8 halves per lane,
+//     + bias + half residual, clamp, one rounding, 16-byte stores.
+// Measured against conv1x1_pipe_kernel<_Float16> (gpurun_out/r03_h256_ab.txt, 16 x 1280^2 ResNeXt-101 shapes, bit-identical
+// outputs): 1024->512 162 -> 132 us, 512->1024 + residual 188 -> 177, 512->256 176 -> 160, 256->512 + residual 265 -> 239,
+// 2048->1024 132 -> 123.  What holds it at ~810-870 TF: the K loop alone (stores ablated) runs at ~900 TF -- one
+// vmcnt(0) + barrier per chunk with the next chunk issued only one chunk ahead -- and a 128 KB tile drains at ~10 B/clk/CU
+// while the block's own MFMAs idle (one block per CU: nothing else to run).  Tried and measured no better: starting
+// blocks a quarter tile apart (s_sleep) so that epilogues overlap other blocks' K loops (132 -> 141 us on 1024->512,
+// 177 -> 172 on 512->1024 + residual); the next tile's chunk 1 issued before the stores with counted waits (kept: -2 %).
+// Numerics: fp16 products are exact in fp32, fp32 accumulation in k order per output, bias / residual / clamp in fp32 --
+// the same arithmetic as conv1x1_pipe_kernel<_Float16> (which chains 64-deep chunks the same way).
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256;                  // block tile
+constexpr int ROWB = 128;                          // bytes of K per staged row and chunk (64 halves)
+constexpr int BUFB = (TM + TN) * ROWB;             // one staging buffer: 64 KB
+constexpr int SCR_LD = 36;                         // floats per row of a wave's transposition scratch
+constexpr int SCRB = 16 * SCR_LD * 4;
+constexpr int H256_LDS = 2 * BUFB + 8 * SCRB;      // 149 504 B
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct H256Args {
+    const void *in, *wgt, *res;
+    const float *bias;
+    void *out;
+    long long M;
+    int K, N;
+    int in_cs, in_coff, out_cs, out_coff;    // elements; the residual shares out_cs / out_coff
+    int panels, G, gshift;                   // 256-row panels; N tiles per panel = G = 1 << gshift
+    int step;                                // panels worked on at the same time = grid >> gshift
+    int xcd_map;
+    float lo, hi;
+    int clamp;
+};
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)dst, 16, voff, soff, 0, 0);
+#endif
+}
+__device__ __forceinline__ unsigned records_left(long long off, long long total) {
+    const unsigned long long left = (unsigned long long)(total - off);
+    const unsigned hi = (unsigned)(left >> 32), lo = (unsigned)left;
+    return (hi & 0x80000000u) ? 0u : (hi ? 0xffffffffu : lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void *ptr, long long off, long long total) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)ptr + off), 0, (int)records_left(off, total), 0x00020000);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// the same descriptor as four plain dwords, for inline-asm operands
+__device__ __forceinline__ i32x4 rsrc_words(const void *ptr, long long off, long long total) {
+    const unsigned long long base = (unsigned long long)((const char *)ptr + off);
+    const i32x4 w = {(int)(unsigned)base, (int)((unsigned)(base >> 32) & 0xffffu), (int)records_left(off, total), 0x00020000};
+    return w;
+}
+// Register-destination load hipcc must not see: beside LDS-direct loads in flight it would wait vmcnt(0) before every
+// use of an ordinary load's result -- i.e. for the previous piece's STORES too.  Completion is waited for by hand.
+__device__ __forceinline__ f32x4 buf_load16_asm(i32x4 rsrc, int voff) {
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_loaded4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+template <bool HAS_RES>
+__global__ void __launch_bounds__(512, 2)
+conv1x1_h256_kernel(const H256Args A) {
+    extern __shared__ __align__(16) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                   // wave tile: rows 128 wr .., columns 64 wc ..
+    const int r = lane & 31, h = lane >> 5;
+    const int swz = (r >> 1) & 7;
+
+    // ---- staging: wave w, piece i (0..3) covers rows 64 i + 8 w .. + 7 of the A tile and of the B tile;
+    // lane -> row lane >> 3, 16-byte group (lane & 7) ^ swizzle key of that row
+    const int ld_r = 8 * wave + (lane >> 3);                   // + 64 i
+    const int ld_g = (lane & 7) ^ ((ld_r >> 1) & 7);           // (64 i does not change the key)
+    int a_voff[4], b_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_voff[i] = ((ld_r + 64 * i) * A.in_cs + A.in_coff) * 2 + ld_g * 16;
+        b_voff[i] = (ld_r + 64 * i) * A.K * 2 + ld_g * 16;
+    }
+    const int a_off = (wr * 128 + r) * ROWB;                   // fragment rows of this lane
+    const int b_off = TM * ROWB + (wc * 64 + r) * ROWB;
+
+    // ---- epilogue ownership inside a 16-row x 32-column piece: lane -> row lane >> 2, columns 8 (lane & 3) .. + 7
+    const int t_row = lane >> 2, t_col = (lane & 3) * 8;
+    char *scratch = lds + 2 * BUFB + wave * SCRB;
+    const int scr_w = (4 * h * SCR_LD + r) * 4;
+    const int scr_r = (t_row * SCR_LD + t_col) * 4;
+
+    const int nk = A.K / 64;
+    const long long in_total = A.M * (long long)A.in_cs * 2;
+    const long long out_total = A.M * (long long)A.out_cs * 2;
+    const long long w_total = (long long)A.N * A.K * 2;
+
+    // ---- which tiles: one N tile (group) for the block's life, panels panel0, panel0 + step, ...
+    const int bid = (int)blockIdx.x;
+    const int gmask = A.G - 1;
+    const int slot = bid >> 3, ppx = A.step >> 3;
+    const int nt = A.xcd_map ? (slot & gmask) : (bid & gmask);
+    int panel = A.xcd_map ? (bid & 7) * ppx + (slot >> A.gshift) : (bid >> A.gshift);
+    if (panel >= A.panels) return;
+
+    const __amdgpu_buffer_rsrc_t rb = rsrc_at(A.wgt, (long long)nt * TN * A.K * 2, w_total);
+    auto res_a = [&](int p) { return rsrc_at(A.in, (long long)p * TM * A.in_cs * 2, p < A.panels ? in_total : 0); };
+    auto stage = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rbb, char *buf, int soff) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(ra, buf + (64 * i + 8 * wave) * ROWB, a_voff[i], soff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rbb, buf + (TM + 64 * i + 8 * wave) * ROWB, b_voff[i], soff);
+    };
+
+    // bias of this wave's 64 columns, in the epilogue's column ownership: 2 sub-tiles x 8 floats
+    f32x4 bias[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = nt * TN + wc * 64 + ni * 32 + t_col + 4 * k;
+            bias[ni][k] = A.bias ? *reinterpret_cast<const f32x4 *>(A.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    __amdgpu_buffer_rsrc_t ra = res_a(panel);
+    stage(ra, rb, lds, 0);                                      // chunk 0 of the first tile
+    int buf = 0;
+    bool pre = false;                 // chunk 1 of the current tile was issued before the previous tile's epilogue
+    for (;;) {
+        const int next_panel = panel + A.step;
+        const __amdgpu_buffer_rsrc_t ra_next = res_a(next_panel);      // (empty past the end: no traffic)
+        f32x16 acc[4][2];
+        for (int kc = 0; kc < nk; ++kc) {
+            // My share of this chunk has landed.  Vector-memory operations retire in issue order, so what may stay in
+            // flight is counted: behind chunk 0 of a `pre` tile sit chunk 1's 8 loads and the previous tile's 16 stores
+            // (with a residual its loads, already waited for, retired everything older than the stores); behind chunk 1
+            // only those stores -- the store drain of a tile (128 KB per CU at ~10 B/clk) overlaps the next tile's first
+            // two chunks instead of stalling its first wait.
+            if (pre && kc == 0) {
+                if constexpr (HAS_RES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else if (pre && kc == 1) {
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                               // ... everyone's; and the other buffer is free
+            const char *rd = lds + buf * BUFB;
+            char *wrb = lds + (buf ^ 1) * BUFB;
+            const bool do_dma = !(pre && kc == 0);                      // (chunk 1 of a `pre` tile is already in flight)
+            const bool more = kc + 1 < nk;
+            const __amdgpu_buffer_rsrc_t ra_nx = more ? ra : ra_next;
+            const __amdgpu_buffer_rsrc_t rb_nx = (more || next_panel < A.panels) ? rb : rsrc_at(A.wgt, 0, 0);
+            const int soff = more ? (kc + 1) * ROWB : 0;
+            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0, 4, 8, ...
+            f32x4 fa[2][4], fb[2][2];
+            auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) {
+                const int slot16 = ((ks * 2 + h) ^ swz) * 16;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd + a_off + m * 32 * ROWB + slot16);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4 *>(rd + b_off + n * 32 * ROWB + slot16);
+            };
+            read_frags(0, fa[0], fb[0]);
+            if (kc == 0) {                                             // a tile's chains start from 0 (once per tile)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+            }
+            static_for<0, 32>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value;               // ks * 8 + mi * 2 + ni
+                constexpr int ks = idx >> 3, mi = (idx >> 1) & 3, ni = idx & 1;
+                if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+                if constexpr ((idx & 3) == 0) {
+                    constexpr int p = idx >> 2;                         // piece 0..7
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (do_dma) {
+                        if constexpr (p < 4) lds_dma16(ra_nx, wrb + (64 * p + 8 * wave) * ROWB, a_voff[p], soff);
+                        else lds_dma16(rb_nx, wrb + (TM + 64 * (p - 4) + 8 * wave) * ROWB, b_voff[p - 4], soff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            buf ^= 1;
+        }
+        // chunk 1 of the NEXT tile goes out before this tile's stores (its buffer, the last chunk's, is free once every
+        // wave has read its fragments): see the counted waits above
+        pre = next_panel < A.panels && nk >= 2;
+        if (pre) {
+            __builtin_amdgcn_s_barrier();
+            stage(ra_next, rb, lds + (buf ^ 1) * BUFB, ROWB);
+        }
+
+        // ---- epilogue of this tile (the next tile's first chunk is already on its way).  Four groups (mi) of four
+        // 16-row x 32-column pieces; the residual of group g + 1 is fetched (inline asm, counted waits) before group g's
+        // stores are issued, so no load ever waits for a store.
+        const long long tile_off = ((long long)panel * TM * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
+        const __amdgpu_buffer_rsrc_t ro = rsrc_at(A.out, tile_off, out_total);
+        const i32x4 rr = rsrc_words(A.res, tile_off, HAS_RES ? out_total : 0);
+        float *sw = reinterpret_cast<float *>(scratch + scr_w);
+        const f32x4 *sr = reinterpret_cast<const f32x4 *>(scratch + scr_r);
+        auto voff_of = [&](int mi, int ni, int hs) {
+            return ((wr * 128 + mi * 32 + hs * 16 + t_row) * A.out_cs + wc * 64 + ni * 32 + t_col) * 2;
+        };
+        f32x4 rq[2][4];
+        auto load_group = [&](int mi, f32x4 (&q)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = buf_load16_asm(rr, voff_of(mi, k >> 1, k & 1));
+        };
+        if constexpr (HAS_RES) load_group(0, rq[0]);
+        static_for<0, 4>([&](auto mc) {
+            constexpr int mi = decltype(mc)::value;
+            if constexpr (HAS_RES) {
+                if constexpr (mi < 3) load_group(mi + 1, rq[(mi + 1) & 1]);
+                // younger than this group's loads: the next group's 4 loads and the previous group's 4 stores
+                constexpr int younger = (mi < 3 ? 4 : 0) + (mi > 0 ? 4 : 0);
+                wait_loaded4<younger>(rq[mi & 1][0], rq[mi & 1][1], rq[mi & 1][2], rq[mi & 1][3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ni = k >> 1, hs = k & 1;
+                // C/D layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)) -> scratch[row][col]
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = hs * 8 + e8;
+                    sw[((e & 3) + 8 * ((e >> 2) & 1)) * SCR_LD] = acc[mi][ni][e];
+                }
+                f32x4 v0 = sr[0], v1 = sr[1];
+                if constexpr (HAS_RES) {
+                    const f16x8 rh = __builtin_bit_cast(f16x8, rq[mi & 1][k]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { v0[c] += (float)rh[c]; v1[c] += (float)rh[4 + c]; }
+                }
+                v0 += bias[ni][0];
+                v1 += bias[ni][1];
+                if (A.clamp) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        v0[c] = __builtin_amdgcn_fmed3f(v0[c], A.lo, A.hi);
+                        v1[c] = __builtin_amdgcn_fmed3f(v1[c], A.lo, A.hi);
+                    }
+                }
+                const f16x8 o = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                                 (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, voff_of(mi, ni, hs), 0, 0);
+            }
+        });
+        if (next_panel >= A.panels) break;
+        panel = next_panel;
+        ra = ra_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool HAS_RES>
+int launch_h256(const H256Args &A, int grid, hipStream_t s) {
+    auto kern = conv1x1_h256_kernel<HAS_RES>;
+    static std::atomic<unsigned long long> ok{0};
+    if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), H256_LDS, ok, "conv1x1_h256")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), H256_LDS, s, A);
+    ML_CHECK_LAUNCH("conv1x1_h256");
+    return ML_OK;
+}
+
+}  // namespace
+
+// 1 when this kernel handles the problem AND is expected to beat conv1x1_pipe_kernel<_Float16> on it
+int ml_conv1x1_h256_eligible(const ml_conv2d_desc &d) {
+    const bool shape_ok = d.math == ML_MATH_F16S && d.out_f16 == 1 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.dil == 1 &&
+                          d.pad_t == 0 && d.pad_l == 0 && d.cpp_shift == 30 && d.group_cin_step == 0 && d.shuffle2x2 == 0 &&
+                          d.out_bstride == 0 && d.Ho == d.H && d.Wo == d.W && !d.live && d.act != ML_ACT_SIGMOID;
+    if (!shape_ok) return 0;
+    if (d.span % 64 != 0 || d.span < 256 || d.cout % 256 != 0 || d.n_pad != d.cout) return 0;
+    const int G = d.cout / 256;
+    if (G > 8 || (G & (G - 1))) return 0;
+    if (d.in_cstride % 8 || d.in_coff % 8 || d.out_cstride % 8 || d.out_coff % 8 || !ml_aligned16(d.in) || !ml_aligned16(d.wgt) ||
+        !ml_aligned16(d.out) || (d.residual && !ml_aligned16(d.residual)) || (d.bias && !ml_aligned16(d.bias)))
+        return 0;
+    if (d.residual && (d.res_cstride != d.out_cstride || d.res_coff != d.out_coff)) return 0;
+    if ((long long)(TM + 8) * d.in_cstride * 2 >= (1ll << 31) || (long long)(TM + 8) * d.out_cstride * 2 >= (1ll << 31)) return 0;
+    const long long M = (long long)d.B * d.H * d.W;
+    const long long tiles = ((M + TM - 1) / TM) * G;
+    return tiles >= ml_resident_blocks(1) ? 1 : 0;                // at least one full round of one block per CU
+}
+
+int ml_conv1x1_h256_try(const ml_conv2d_desc &d, hipStream_t s, int *took) {
+    *took = 0;
+    if (!ml_conv1x1_h256_eligible(d)) return ML_OK;
+    const long long M = (long long)d.B * d.H * d.W;
+    H256Args A;
+    A.in = d.in; A.wgt = d.wgt; A.bias = d.bias; A.res = d.residual; A.out = d.out;
+    A.M = M; A.K = d.span; A.N = d.cout;
+    A.in_cs = d.in_cstride; A.in_coff = d.in_coff; A.out_cs = d.out_cstride; A.out_coff = d.out_coff;
+    A.panels = (int)((M + TM - 1) / TM);
+    A.G = d.cout / 256;
+    A.gshift = 0;
+    while ((1 << A.gshift) < A.G) ++A.gshift;
+    const int resident = ml_resident_blocks(1);                  // one 8-wave block per CU (256 on MI355X; a multiple of 32)
+    const long long units = (long long)A.panels * A.G;
+    int grid = units < resident ? (int)units : resident / A.G * A.G;
+    A.xcd_map = (A.G > 1 && grid % (8 * A.G) == 0) ? 1 : 0;
+    A.step = grid >> A.gshift;
+    A.clamp = d.act != ML_ACT_NONE;
+    A.lo = 0.f;
+    A.hi = d.act == ML_ACT_RELU6 ? 6.f : 3.402823466e38f;
+    const int rc = d.residual ? launch_h256<true>(A, grid, s) : launch_h256<false>(A, grid, s);
+    if (rc != ML_OK) return rc;
+    *took = 1;
+    return ML_OK;
+}

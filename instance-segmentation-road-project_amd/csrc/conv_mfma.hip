@@ -186,7 +186,9 @@ conv_mfma_kernel(const MultiArgs args) {
     // (round-robin panels measured 2.0x the algorithmic HBM bytes on the tower convs, profiles/r02a_traffic.json).
     const int xcd = id & 7;
     const int jj = id >> 3;
-    const int mt = (p.KH > 1) ? xcd * ((P.MB + 7) >> 3) + jj / NB : (jj / NB) * 8 + xcd;
+    // (fixed-capacity RoI batches keep round-robin panels: their live tiles are the FIRST slots of every image, which a
+    // contiguous split would pile onto a few XCDs -- 129 us instead of ~45 for the 1-image mask head)
+    const int mt = (p.KH > 1 && !p.live) ? xcd * ((P.MB + 7) >> 3) + jj / NB : (jj / NB) * 8 + xcd;
     const int nt = jj % NB;
     if (mt >= P.MB) return;
     const int m0 = mt * BM;
@@ -661,6 +663,7 @@ splitk_reduce_kernel(const ReduceArgs args) {
     const int m = (int)(idx / V);
     const int n = (int)(idx % V) * 4;
     if (n >= p.cout) return;
+    if (p.live && (m / (p.Ho * p.Wo)) % p.live_period >= max(1, *p.live)) return;      // a row of an image that does not exist
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < splits; ++s)
         v += *reinterpret_cast<const f32x4 *>(slab + ((size_t)s * m_pad + m) * p.n_pad + n);
@@ -669,7 +672,7 @@ splitk_reduce_kernel(const ReduceArgs args) {
 }
 
 int pick_tile(int cout, int tile) {
-    if (tile == 4) return 1;          // the pipelined 1x1 kernel works on 128x128 tiles like tile 1
+    if (tile == 4 || tile == 5) return 1;   // the pipelined 1x1 kernels (4: 128x128 tiles; 5: the half 256x256 one) pack like tile 1
     if (tile >= 1 && tile <= 3) return tile;
     if (cout <= 32) return 3;
     if (cout <= 64) return 2;
@@ -771,10 +774,15 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     long long start = 0, ws_off = 0;
     // split-K looks at the whole launch: five pyramid levels of one image are 171 tiles together -- a third of
     // the chip -- and each tile then walks all 36 chunks alone (92 us); slicing K fills the other CUs
+    // Fixed-capacity RoI batches (`live`): an image's RoIs are spread over the launch's RoI levels, so about 1 / levels
+    // of the nominal tiles are live -- the split decision is taken on that estimate (the host does not know the counts).
     long long launch_tiles = 0;
+    int n_live = 0;
+    for (int i = 0; i < n; ++i) n_live += descs[i].live != nullptr;
     for (int i = 0; i < n; ++i) {
         const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
-        launch_tiles += ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
+        const long long t = ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
+        launch_tiles += descs[i].live ? (t + n_live - 1) / n_live : t;
     }
     if (split_tiles >= 0) launch_tiles = split_tiles;
     for (int i = 0; i < n; ++i) {
@@ -837,13 +845,20 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
 }  // namespace
 
 int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible);     // conv1x1_pipe.hip
+int ml_conv1x1_h256_try(const ml_conv2d_desc &d, hipStream_t s, int *took);          // conv1x1_h256.hip
+int ml_conv1x1_h256_eligible(const ml_conv2d_desc &d);
+// half tensors: where the 256 x 256-tile kernel is preferred over the 128 x 128 pipelined one (per-launch A/B,
+// gpurun_out/r03_h256_ab.txt): K >= 512, or K >= 256 with at least two 256-wide N tiles
+static bool h256_preferred(const ml_conv2d_desc &d) {
+    return d.tile == 5 || (d.tile == 0 && (d.span >= 512 || (d.span >= 256 && d.cout >= 512)));
+}
 
 extern "C" int ml_conv2d_ntile(int32_t cout, int32_t tile) {
     const int t = pick_tile(cout, tile);
     return t == 1 ? 128 : (t == 2 ? 64 : 32);
 }
 
-extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 64ll << 20; }
+extern "C" int64_t ml_conv2d_workspace_bytes(void) { return 512ll << 20; }   // (split-K slabs of fixed-capacity RoI batches are sized for every slot)
 
 int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d);                               // conv1x1_pipe.hip
 // fp16 storage: the persistent kernel takes every 1x1 problem it can run, except those the generic kernel would cut
@@ -858,6 +873,7 @@ static bool pipe_preferred_half(const ml_conv2d_desc &d) {
 
 extern "C" int ml_conv2d_uses_pipe(const ml_conv2d_desc *d) {
     if (!d) return 0;
+    if (d->math == ML_MATH_F16S && h256_preferred(*d) && ml_conv1x1_h256_eligible(*d)) return 2;
     if (d->math == ML_MATH_F16S) return pipe_preferred_half(*d) && ml_conv1x1_pipe_eligible(*d);
     if (d->tile == 4) return ml_conv1x1_pipe_eligible(*d);
     return d->tile == 0 && pipe_preferred(*d) && ml_conv1x1_pipe_eligible(*d);
@@ -908,18 +924,23 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
     if (t0 == 3) return t0;
     const int ref_bn = t0 == 1 ? 128 : 64;
     long long tiles = 0;
+    int n_live = 0;
+    for (int i = 0; i < n; ++i) n_live += descs[i].live != nullptr;
+    auto tiles_of = [&](const ml_conv2d_desc &d) {          // (live problems: the estimate launch_multi uses)
+        const long long M = (long long)d.B * d.Ho * d.Wo;
+        const long long t = ((M + 127) / 128) * (d.n_pad / ref_bn);
+        return d.live ? (t + n_live - 1) / n_live : t;
+    };
     for (int i = 0; i < n; ++i) {
         if (descs[i].group_cin_step) return t0;
-        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
-        tiles += ((M + 127) / 128) * (descs[i].n_pad / ref_bn);
+        tiles += tiles_of(descs[i]);
     }
     long long blocks = 0;
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
-        const long long M = (long long)d.B * d.Ho * d.Wo;
         const int chunks = d.KH * d.KW * (d.span_pad / (d.math == ML_MATH_F16S ? 64 : 32));
         const int splits = have_ws ? choose_splits(tiles, chunks) : 1;
-        blocks += ((M + 127) / 128) * (d.n_pad / ref_bn) * splits;
+        blocks += tiles_of(d) * splits;
     }
     const long long resident = ml_resident_blocks(2);
     *ref_tiles = tiles;
@@ -933,13 +954,19 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
                                    void *stream) {
     ML_REQUIRE(descs_in != nullptr && n_in >= 1 && n_in <= MAXP, "conv2d: need 1..%d problems", MAXP);
     // the persistent 1x1 kernel has no tensor-size limit: try it before any splitting
-    if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4)) {
+    if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4 || descs_in[0].tile == 5)) {
         const int rc0 = validate(descs_in[0], false);
         if (rc0 != ML_OK) return rc0;
         ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16 || descs_in[0].math == ML_MATH_F16S,
                    "conv2d: unknown math mode %d", descs_in[0].math);
         int took = 0;
         const bool half = descs_in[0].math == ML_MATH_F16S;
+        if (half && h256_preferred(descs_in[0])) {
+            const int rc = ml_conv1x1_h256_try(descs_in[0], reinterpret_cast<hipStream_t>(stream), &took);
+            if (rc != ML_OK) return rc;
+            if (took) return ML_OK;
+            ML_REQUIRE(descs_in[0].tile != 5, "conv2d: tile = 5 (256 x 256 half kernel) does not apply to this problem");
+        }
         if (half ? pipe_preferred_half(descs_in[0]) : (descs_in[0].tile == 4 || pipe_preferred(descs_in[0]))) {
             const int rc = ml_conv1x1_pipe_try(descs_in[0], reinterpret_cast<hipStream_t>(stream), &took);
             if (rc != ML_OK) return rc;

@@ -244,8 +244,10 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
                                                 in_coff, out_view, out_dtype)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
     name = _conv_kernel_name(dc.p, C.byref(d), 1, half=x.dtype == torch.float16)
-    if PROFILE is not None and lib.ml_conv2d_uses_pipe(C.byref(d)):
-        name = "conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe"
+    if PROFILE is not None:
+        which = lib.ml_conv2d_uses_pipe(C.byref(d))          # 1: the 128 x 128 pipelined kernel, 2: the half 256 x 256 one
+        if which:
+            name = "conv1x1_h256_h" if which == 2 else ("conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe")
     with _Prof(name, flops, nbytes, shape):
         _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret

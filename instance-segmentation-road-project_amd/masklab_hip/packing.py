@@ -43,8 +43,8 @@ def resolve_padding(H, W, kh, kw, stride, dilation, padding):
 
 def ntile_for(cout, tile=0):
     """N-tile width of the MFMA conv kernel's auto heuristic (mirrors ml_conv2d_ntile)."""
-    if tile in (1, 2, 3, 4):          # 4 = the pipelined 1x1 kernel (128-wide tiles like 1)
-        return {1: 128, 2: 64, 3: 32, 4: 128}[tile]
+    if tile in (1, 2, 3, 4, 5):       # 4 / 5 = the pipelined 1x1 kernels (packed in 128-wide tiles like 1)
+        return {1: 128, 2: 64, 3: 32, 4: 128, 5: 128}[tile]
     if cout <= 32:
         return 32
     if cout <= 64:

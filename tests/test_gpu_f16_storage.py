@@ -162,3 +162,39 @@ def test_full_forward_half_storage_close_to_fp32_oracle(bt):
         worst[name] = float(np.abs(g.astype(np.float64) - r).max())
         assert worst[name] <= F16_MODEL_TOL, (name, worst[name])
     assert max(worst.values()) > 1e-6, "suspiciously exact: the fp16 path did not run"
+
+
+@pytest.mark.parametrize("cin,cout,hw,B,res,act", [
+    (1024, 512, (80, 80), 11, False, "relu"),        # ResNeXt-101 stage 3 conv1: 275 panels x 2 N tiles (XCD map), 16 chunks
+    (512, 1024, (80, 80), 11, True, "relu"),         # conv3 + half residual: 4 N tiles per panel
+    (256, 512, (67, 61), 9, True, "relu6"),          # ragged M (36 783 rows = 143.7 panels), 4 chunks
+    (512, 256, (96, 96), 8, False, None),            # one N tile per panel, no clamp
+    (1024, 2048, (40, 40), 16, True, "relu"),        # 8 N tiles per panel
+])
+def test_conv1x1_h256_half_storage(cin, cout, hw, B, res, act):
+    """csrc/conv1x1_h256.hip (half tensors, 256 x 256 tiles, the K >= 256 bottleneck convs of BASELINE configs[4]):
+    against the oracle on identically rounded operands, AND bit for bit against conv1x1_pipe_kernel<_Float16> (the same
+    k-ordered fp32 chains, residual then bias, one rounding)."""
+    from masklab_hip import _lib, ops, packing
+    lib = _lib.load()
+    x = to_half(rnd(B, hw[0], hw[1], cin))
+    w, b = rnd(1, 1, cin, cout, scale=1.0 / np.sqrt(cin)), rnd(cout)
+    r = to_half(rnd(B, hw[0], hw[1], cout)) if res else None
+    outs = {}
+    for tile in (5, 4, 0):
+        dc = ops.DeviceConv(packing.pack_dense(w, b, tile=tile), "cuda")
+        outs[tile] = host(ops.conv2d(dev(x), dc, padding="valid", act=_lib.ACT_BY_NAME[act], residual=dev(r) if res else None))
+    np.testing.assert_array_equal(outs[5], outs[4])
+    np.testing.assert_array_equal(outs[0], outs[5])            # (what the automatic choice runs gives the same bits)
+    sub = slice(0, 2)                                           # oracle on the first two images (it is a CPU conv)
+    ref = T.conv2d(x[sub].astype(np.float64), h64(w), b.astype(np.float64), 1, "valid", 1)
+    if res:
+        ref = ref + r[sub].astype(np.float64)
+    ref = ACT[act](ref).astype(np.float16)
+    np.testing.assert_allclose(outs[5][sub].astype(np.float32), ref.astype(np.float32), rtol=HALF_RTOL, atol=HALF_ATOL)
+    last = slice(B - 1, B)                                      # ... and on the last one (the ragged tail panel)
+    ref = T.conv2d(x[last].astype(np.float64), h64(w), b.astype(np.float64), 1, "valid", 1)
+    if res:
+        ref = ref + r[last].astype(np.float64)
+    ref = ACT[act](ref).astype(np.float16)
+    np.testing.assert_allclose(outs[5][last].astype(np.float32), ref.astype(np.float32), rtol=HALF_RTOL, atol=HALF_ATOL)
