@@ -106,6 +106,12 @@ typedef struct ml_conv2d_desc {
                                non-existing images compute and store nothing.  Generic kernel only.        */
     int32_t live_period;    /* RoI slots per image (B % live_period == 0); ignored when live == NULL      */
     int32_t reserved1;
+    double *gn_partials;    /* NULL, or [ceil(M/128)][4][2] DEVICE doubles: the epilogue also writes (sum, sum of squares)
+                               of the values each 128-row tile stores, one pair per wave of the block (4 per tile) --
+                               what the GroupNormalization behind a head conv
+                               needs (detection.py:120-125): ml_gn_desc.partials then replaces the statistics pass.
+                               fp32, cout = n_pad = 128, M % 128 == 0, dense destination, no residual, and a launch
+                               that is neither narrowed nor split along K (>= 257 tiles in all)                 */
 } ml_conv2d_desc;
 
 int ml_conv2d_f32(const ml_conv2d_desc *d, void *stream);
@@ -255,6 +261,10 @@ typedef struct ml_gn_desc {
     const int32_t *live;           /* NULL, or a device int: sample n exists iff n % live_period < max(1, *live)
                                       (fixed-capacity RoI batches, as ml_conv2d_desc.live); others are skipped   */
     int32_t live_period, reserved;
+    const double *partials;        /* NULL, or per chunk (n * G + g) `n_partials` consecutive (sum, sum of squares) pairs
+                                      written by the producing conv (ml_conv2d_desc.gn_partials: the chunk's 128-row
+                                      tiles, HWC/G a multiple of 128 * C): added in that order, no statistics pass    */
+    int32_t n_partials, reserved2;
 } ml_gn_desc;
 #define ML_GN_MAX_PROBLEMS 8
 int ml_groupnorm_multi_f32(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t workspace_bytes, void *stream);

@@ -306,7 +306,7 @@ int launch_h256(const H256Args &A, int grid, hipStream_t s) {
 int ml_conv1x1_h256_eligible(const ml_conv2d_desc &d) {
     const bool shape_ok = d.math == ML_MATH_F16S && d.out_f16 == 1 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.dil == 1 &&
                           d.pad_t == 0 && d.pad_l == 0 && d.cpp_shift == 30 && d.group_cin_step == 0 && d.shuffle2x2 == 0 &&
-                          d.out_bstride == 0 && d.Ho == d.H && d.Wo == d.W && !d.live && d.act != ML_ACT_SIGMOID;
+                          d.out_bstride == 0 && d.Ho == d.H && d.Wo == d.W && !d.live && !d.gn_partials && d.act != ML_ACT_SIGMOID;
     if (!shape_ok) return 0;
     if (d.span % 64 != 0 || d.span < 256 || d.cout % 256 != 0 || d.n_pad != d.cout) return 0;
     const int G = d.cout / 256;

@@ -479,7 +479,7 @@ int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d) {
     const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.dil == 1 && d.pad_t == 0 && d.pad_l == 0 &&
                           d.cpp_shift == 30 && d.group_cin_step == 0 && d.shuffle2x2 == 0 && d.out_bstride == 0 &&
                           (d.math == ML_MATH_F32 || f16s) && d.Ho == d.H && d.Wo == d.W;
-    if (!shape_ok || d.live) return 0;
+    if (!shape_ok || d.live || d.gn_partials) return 0;
     if (f16s && !d.out_f16) return 0;                     // this kernel stores the tensor type it reads (fp32 predictions: generic kernel)
     if (!f16s && d.out_f16) return 0;
     if (d.span % kc != 0 || d.cout % 128 != 0 || d.n_pad != d.cout) return 0;

@@ -155,8 +155,13 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
 // prefetch pieces are the f32 code with the element size changed; a chunk is 4 k-steps of v_mfma_f32_32x32x16_f16
 // (one ds_read_b128 = the 8 halves a lane feeds).  Accumulation, bias and activation are fp32; the output is half
 // (`out_f16`, one rounding at the store) or fp32 (the prediction tensors detect.hip reads).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH>
-__global__ void __launch_bounds__(256)
+// GNS = the conv -> (activation) -> GroupNormalization pairs of the heads (engine/layers/detection.py:120-125,
+// semantic.py:205-213): the epilogue also sums its tile's stored values (sum, sum of squares: a float4 folded in fp32, then
+// fp64 -- the same folding as gn_stats_kernel) and writes one pair per WAVE (4 per tile) to `gn_partials`; the GroupNorm
+// apply pass adds the pairs of a chunk's tiles in order instead of re-reading the tensor (csrc/groupnorm.hip).  A separate
+// instantiation: the kernel every other conv runs is untouched.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false>
+__global__ void __launch_bounds__(256, GNS ? 2 : 1)      // (GNS: keep two blocks per CU -- 262 registers otherwise)
 conv_mfma_kernel(const MultiArgs args) {
     constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
     constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
@@ -595,6 +600,7 @@ conv_mfma_kernel(const MultiArgs args) {
         } else if (full && !late_res && !p.out_bstride) {
             float *op = p.out + off;
             const size_t step = (size_t)ROWS_PER_PASS * cs;
+            double gs = 0.0, gq = 0.0;
 #pragma unroll
             for (int i = 0; i < E_ROWS; ++i) {
                 f32x4 v = tile_v[i];
@@ -604,6 +610,26 @@ conv_mfma_kernel(const MultiArgs args) {
                     for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
                 }
                 *reinterpret_cast<f32x4 *>(op + (size_t)i * step) = v;
+                if constexpr (GNS) {
+                    const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                    gs += (double)s4;
+                    gq += (double)q4;
+                }
+            }
+            if constexpr (GNS) {
+                if (p.gn_partials) {                           // (block-uniform)
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        gs += __shfl_down(gs, o, 64);
+                        gq += __shfl_down(gq, o, 64);
+                    }
+                    // one pair per WAVE (a tile's rows 2w, 2w + 1 mod 8): no cross-wave step, no barrier
+                    if (lane == 0) {
+                        p.gn_partials[2 * ((size_t)mt * 4 + wave)] = gs;
+                        p.gn_partials[2 * ((size_t)mt * 4 + wave) + 1] = gq;
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -755,7 +781,7 @@ int choose_splits(long long tiles, int chunks) {
 
 // split_tiles >= 0: the tile count the split-K decision is taken on (see narrow_tile_for_small_launch), else this
 // launch's own
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s,
                  long long split_tiles = -1) {
     constexpr int BM = WAVES_M * TM * 32;
@@ -766,7 +792,7 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
     constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     constexpr int LDS_BYTES = LDS_BYTES0;
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH>;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH, GNS>;
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "conv2d")) return rc;
     MultiArgs args;
@@ -804,6 +830,11 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         int splits = workspace ? choose_splits(launch_tiles, chunks) : 1;     // (the reduce kernel stores half too)
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
         if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
+        if (d.gn_partials)
+            ML_REQUIRE(GNS && splits == 1 && BN == 128 && d.cout == 128 && d.n_pad == 128 && M % BM == 0 && !d.residual &&
+                           !d.out_bstride && !d.out_f16 && !d.shuffle2x2 && d.act != ML_ACT_SIGMOID && !d.live,
+                       "conv2d: gn_partials needs a launch that is neither narrowed nor split along K (>= 257 tiles of 128 x 128), "
+                       "cout = 128, whole 128-row tiles, a dense fp32 destination and no residual");
         P.cps = (chunks + splits - 1) / splits;
         P.splits = (chunks + P.cps - 1) / P.cps;     // drop empty trailing slices
         P.slab = nullptr;
@@ -1011,6 +1042,11 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
             default: return launch_multi<4, 1, 1, 1, ML_MATH_F16>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         }
     }
+    bool any_gns = false;
+    for (int i = 0; i < n; ++i) any_gns = any_gns || descs[i].gn_partials != nullptr;
+    ML_REQUIRE(!any_gns || (t == 1 && descs[0].math == ML_MATH_F32),
+               "conv2d: gn_partials needs the fp32 128 x 128 kernel (a launch of >= 257 tiles)");
+    if (any_gns) return launch_multi<2, 2, 2, 2, ML_MATH_F32, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
     switch (t) {
         case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);

@@ -120,14 +120,15 @@ template <class T, bool VEC4 = true>
 __device__ __forceinline__ void gn_apply_body(const T *x, T *y, const float *__restrict__ gamma,
                                               const float *__restrict__ beta, const double *__restrict__ ws, long long L,
                                               long long slice, int S, int C, int G, float eps, int relu, int out_cs,
-                                              int out_co, int ng, int s) {
+                                              int out_co, int ng, int s, int Sp = -1) {
     constexpr int W = VW<T>::value;
     const int g = ng % G;
     const int cg = C / G;
+    if (Sp < 0) Sp = S;
     double sum = 0, sq = 0;
-    for (int i = 0; i < S; ++i) {  // uniform, L2-resident, S <= 64
-        sum += ws[((long long)ng * S + i) * 2 + 0];
-        sq += ws[((long long)ng * S + i) * 2 + 1];
+    for (int i = 0; i < Sp; ++i) {  // uniform, L2-resident, fixed order
+        sum += ws[((long long)ng * Sp + i) * 2 + 0];
+        sq += ws[((long long)ng * Sp + i) * 2 + 1];
     }
     const double meand = sum / (double)L;
     double vard = sq / (double)L - meand * meand;
@@ -329,6 +330,7 @@ struct GnProb {
     double *ws;               // partials of this problem (two-pass only)
     long long L, slice;
     int NG, S, C, G, relu, out_cs, out_co, onepass_vpt;   // onepass_vpt: 0 = two-pass, else float4 per thread
+    int Sp;                   // (sum, sum of squares) pairs per chunk in `ws`: S from gn_stats, or the producing conv's tiles
     float eps;
     const int *live;          // fixed-capacity RoI batches: sample n is live iff n % live_period < max(1, *live)
     int live_period;
@@ -365,7 +367,7 @@ gn_multi_apply_kernel(const GnMulti A) {
     if (gn_dead(P, P.onepass_vpt == 0 ? id / P.S : id)) return;          // (block-uniform)
     if (P.onepass_vpt == 0) {
         gn_apply_body<T>(x, y, P.gamma, P.beta, P.ws, P.L, P.slice, P.S, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co,
-                         id / P.S, id % P.S);
+                         id / P.S, id % P.S, P.Sp);
     } else if (P.onepass_vpt == 1) {
         gn_onepass_body<T, GN_TPB, 1>(x, y, P.gamma, P.beta, (int)P.L, P.C, P.G, P.eps, P.relu, P.out_cs, P.out_co, id);
     } else if (P.onepass_vpt == 2) {
@@ -416,12 +418,22 @@ static int gn_multi(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t
         P.eps = d.eps;
         P.live = d.live; P.live_period = d.live_period;
         if (d.live) ML_REQUIRE(d.live_period >= 1 && d.N % d.live_period == 0, "groupnorm_multi: live_period must divide N");
-        P.ws = nullptr; P.S = 1; P.slice = L; P.onepass_vpt = 0;
+        P.ws = nullptr; P.S = 1; P.slice = L; P.onepass_vpt = 0; P.Sp = -1;
         if (L <= GN_ONEPASS_MAX) {
             const int vn = (int)((L + W - 1) / W);
             P.onepass_vpt = vn <= 256 ? 1 : (vn <= 512 ? 2 : 4);
             ap.start[i] = (int)ab;
             ab += P.NG;
+        } else if (d.partials) {
+            // the producing conv summed its tiles (ml_conv2d_desc.gn_partials): no statistics pass over this tensor
+            ML_REQUIRE(d.n_partials >= 1 && d.n_partials <= 4096 && d.dtype == 0,
+                       "groupnorm_multi: problem %d: 1..4096 fp64 (sum, sum of squares) pairs per chunk, float tensors", i);
+            const GnPlan plan = gn_plan(L, P.NG, W);
+            P.S = plan.S; P.slice = plan.slice;
+            P.ws = const_cast<double *>(d.partials);
+            P.Sp = d.n_partials;
+            ap.start[i] = (int)ab;
+            ab += (long long)P.NG * P.S;
         } else {
             const GnPlan plan = gn_plan(L, P.NG, W);
             P.S = plan.S; P.slice = plan.slice;

@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("tile", C.c_int32), ("math", C.c_int32), ("out_f16", C.c_int32),
         ("out_bstride", C.c_int64),
         ("live", C.c_void_p), ("live_period", C.c_int32), ("reserved1", C.c_int32),
+        ("gn_partials", C.c_void_p),
     ]
 
 
@@ -42,7 +43,8 @@ class GnDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("HWC", C.c_int64), ("N", C.c_int32), ("C", C.c_int32), ("G", C.c_int32), ("relu", C.c_int32),
                 ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32),
-                ("live", C.c_void_p), ("live_period", C.c_int32), ("reserved", C.c_int32)]
+                ("live", C.c_void_p), ("live_period", C.c_int32), ("reserved", C.c_int32),
+                ("partials", C.c_void_p), ("n_partials", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class DeconvOutProblem(C.Structure):

@@ -238,12 +238,12 @@ class Conv2D(Layer):
     def _load_own(self, weights, device):
         self.dev = ops.DeviceConv(self.pack(weights), device)
 
-    def call(self, x, residual=None, out=None, out_coff=0, out_dtype=None, **kwargs):
+    def call(self, x, residual=None, out=None, out_coff=0, out_dtype=None, gn_partials=None, **kwargs):
         if self.dev is None:
             raise RuntimeError(f"layer '{self.name}' has no weights loaded")
         return ops.conv2d(x, self.dev, stride=self.strides[0], padding=self.padding,
                           dilation=self.dilation_rate[0], act=_lib.ACT_BY_NAME[self.activation],
-                          residual=residual, out=out, out_coff=out_coff, out_dtype=out_dtype)
+                          residual=residual, out=out, out_coff=out_coff, out_dtype=out_dtype, gn_partials=gn_partials)
 
     def get_config(self):
         c = super().get_config()

@@ -93,9 +93,31 @@ class _TowerMixin:
         return block
 
     @staticmethod
+    def _conv_tiles(c, x):
+        """128 x 128 tiles of conv `c` on input `x` (the library's split-K / narrow-tile decisions look at this count)."""
+        from ..packing import resolve_padding
+        Ho, Wo, _, _ = resolve_padding(int(x.shape[1]), int(x.shape[2]), c.kernel_size[0], c.kernel_size[1], c.strides[0],
+                                       c.dilation_rate[0], c.padding)
+        return -(-int(x.shape[0]) * Ho * Wo // 128) * (c.dev.p.n_pad // 128 if c.dev.p.n_pad >= 128 else 1), (int(x.shape[0]), Ho, Wo)
+
+    @staticmethod
     def _run_tower(block, x):
         block_input = x                          # never modified in place (it is a caller's tensor)
-        for layer in block:
+        i = 0
+        while i < len(block):
+            layer = block[i]
+            nxt = block[i + 1] if i + 1 < len(block) else None
+            if isinstance(layer, Conv2D) and isinstance(nxt, GroupNormalization) and layer.dev is not None:
+                # conv -> (ReLU) -> GroupNormalization: the conv's epilogue sums its tiles, no statistics pass (fp32, big maps)
+                tiles, oshape = _TowerMixin._conv_tiles(layer, x)
+                tpc = ops.gn_fusable(oshape, layer.filters, nxt.groups, layer.dev, tiles, x.dtype)
+                if tpc:
+                    part = torch.empty((tiles, 4, 2), dtype=torch.float64, device=x.device)
+                    x = layer(x, gn_partials=part)
+                    x = GroupNormalization.call_multi([nxt], [x], inplace=True, partials=[(part, tpc)])[0]
+                    i += 2
+                    continue
+            i += 1
             if isinstance(layer, GroupNormalization):
                 x = layer(x, inplace=True)      # conv output is a fresh tensor: normalise in place
             elif isinstance(layer, SqueezeExcite):
@@ -120,13 +142,25 @@ class _TowerMixin:
             return [_TowerMixin._run_tower(b, x) for b, x in zip(blocks, xs)]
         xs = list(xs)
         lives = lives if lives is not None else [None] * len(xs)
+        no_lives = all(lv is None for lv in lives)
         for i in range(len(blocks[0]) // 2):
             convs = [b[2 * i] for b in blocks]
+            norms = [b[2 * i + 1] for b in blocks]
+            # levels whose GroupNorm chunks are whole conv tiles take their statistics from the conv's epilogue
+            parts = [None] * len(xs)
+            if no_lives:
+                geo = [_TowerMixin._conv_tiles(c, x) for c, x in zip(convs, xs)]
+                launch_tiles = sum(t for t, _ in geo)
+                for k, (c, g, x, (t, oshape)) in enumerate(zip(convs, norms, xs, geo)):
+                    tpc = ops.gn_fusable(oshape, c.filters, g.groups, c.dev, launch_tiles, x.dtype)
+                    if tpc:
+                        parts[k] = (torch.empty((t, 4, 2), dtype=torch.float64, device=x.device), tpc)
             xs = ops.conv2d_multi([dict(x=x, dc=c.dev, stride=c.strides[0], padding=c.padding,
-                                        dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation], live=lv)
-                                   for c, x, lv in zip(convs, xs, lives)])
-            xs = GroupNormalization.call_multi([b[2 * i + 1] for b in blocks], xs, inplace=True,
-                                               lives=None if all(lv is None for lv in lives) else lives)
+                                        dilation=c.dilation_rate[0], act=ops._lib.ACT_BY_NAME[c.activation], live=lv,
+                                        gn_partials=None if pt is None else pt[0])
+                                   for c, x, lv, pt in zip(convs, xs, lives, parts)])
+            xs = GroupNormalization.call_multi(norms, xs, inplace=True, lives=None if no_lives else lives,
+                                               partials=None if all(pt is None for pt in parts) else parts)
         return xs
 
     @staticmethod

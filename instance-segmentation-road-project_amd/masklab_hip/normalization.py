@@ -68,14 +68,15 @@ class GroupNormalization(Layer):
                                    out=inputs if inplace else None)
 
     @staticmethod
-    def call_multi(layers, inputs, inplace=False, lives=None):
+    def call_multi(layers, inputs, inplace=False, lives=None, partials=None):
         """The same layers applied to their own inputs in ONE launch pair (the un-shared towers normalise five pyramid
         levels at every depth, reference engine/layers/detection.py:124,194): results identical to calling each.
         lives: per input None or (device int32 [1], slots per image) -- a fixed-capacity RoI batch whose samples past
         max(1, live) per image do not exist and are skipped."""
         probs = []
         lives = lives if lives is not None else [None] * len(inputs)
-        for layer, x, live in zip(layers, inputs, lives):
+        partials = partials if partials is not None else [None] * len(inputs)   # per input None or (float64 pairs, per chunk)
+        for layer, x, live, part in zip(layers, inputs, lives, partials):
             if not layer.built:
                 layer.build(tuple(x.shape))
             if (layer.scale and layer.gamma is None) or (layer.center and layer.beta is None):
@@ -87,7 +88,7 @@ class GroupNormalization(Layer):
                     raise NotImplementedError("GroupNormalization: fixed-capacity batches need vectorisable chunks")
                 return [l(x_, inplace=inplace) for l, x_ in zip(layers, inputs)]
             probs.append(dict(x=x, gamma=layer.gamma, beta=layer.beta, groups=layer.groups, eps=layer.epsilon,
-                              out=x if inplace else None, live=live))
+                              out=x if inplace else None, live=live, partials=part))
         return ops.groupnorm_chunk_multi(probs)
 
     def get_config(self):

@@ -132,7 +132,7 @@ class DeviceConv:
 
 
 def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, residual=None, out=None,
-               out_coff=0, in_coff=0, out_view=None, out_dtype=None, live=None):
+               out_coff=0, in_coff=0, out_view=None, out_dtype=None, live=None, gn_partials=None):
     """Build the ml_conv2d_desc for one problem.  -> (desc, result tensor, profile record args).
     A float16 `x` selects the fp16-storage kernels (ML_MATH_F16S: half weights, half residual); the output is half
     unless the destination says otherwise (`out` / `out_view` tensor of dtype float32, out_dtype=torch.float32, or a
@@ -199,6 +199,11 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
     d.KH, d.KW, d.stride, d.dil, d.pad_t, d.pad_l = p.KH, p.KW, stride, dilation, pt, pl
     d.cout, d.n_pad = p.cout, p.n_pad
     d.act, d.group_cin_step, d.shuffle2x2, d.tile = act, p.group_cin_step, p.shuffle2x2, p.tile
+    if gn_partials is not None:        # float64 [tiles, 4, 2]: the epilogue also sums what each 128-row tile stores (per wave)
+        _require_dev(gn_partials, "gn_partials")
+        if gn_partials.dtype != torch.float64 or gn_partials.numel() < 8 * ((B * Ho * Wo + 127) // 128):
+            raise ValueError("conv2d: gn_partials must be a float64 tensor of 4 x 2 values per 128-row tile")
+        d.gn_partials = gn_partials.data_ptr()
     if live is not None:               # (device int32 tensor [1], slots per image): a fixed-capacity RoI batch
         lv, period = live
         _require_dev(lv, "live")
@@ -229,8 +234,22 @@ def _conv_kernel_name(p, descs=None, n=1, half=False):
                                      "_h" if half else ("_f16" if CONV_MATH != "f32" else ""))
 
 
+def gn_fusable(out_shape, C_out, groups, dc, launch_tiles, dtype):
+    """Can the GroupNormalization behind this conv take its statistics from the conv's epilogue (ml_conv2d_desc.gn_partials)?
+    out_shape = (B, Ho, Wo): whole 128-row tiles per image and per chunk, one 128-wide N tile, fp32, and a launch big
+    enough that the library neither narrows its tiles nor cuts K (>= 257 tiles of 128 x 128 in all).
+    -> (sum, sum of squares) pairs per chunk (4 per tile: one per wave), or 0."""
+    B, Ho, Wo = out_shape
+    hw = Ho * Wo
+    p = dc.p
+    ok = (CONV_MATH == "f32" and dtype == torch.float32 and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
+          not p.shuffle2x2 and not p.group_cin_step and hw % 128 == 0 and hw % groups == 0 and (hw // groups) % 128 == 0 and
+          launch_tiles >= 257)
+    return 4 * ((hw // groups) // 128) if ok else 0
+
+
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
-           residual=None, out=None, out_coff=0, in_coff=0, out_view=None, out_dtype=None):
+           residual=None, out=None, out_coff=0, in_coff=0, out_view=None, out_dtype=None, gn_partials=None):
     """ml_conv2d_multi_f32 with one problem (split-K enabled through the shared workspace).
     `x` [B,H,W,Cbuf]; reads channels [in_coff, in_coff+cin).  Writes into
     `out[..., out_coff:out_coff+cout]` when given, else allocates.  `out_view=(tensor, elem_off,
@@ -241,7 +260,7 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
         # a strided 1x1 conv on half tensors = the stride-1 kernel on the sampled pixels (ResNext.py:199-203 shortcuts)
         x, stride = subsample2_h(x), 1
     d, ret, (flops, nbytes, shape) = _conv_desc(x, dc, stride, padding, dilation, act, residual, out, out_coff,
-                                                in_coff, out_view, out_dtype)
+                                                in_coff, out_view, out_dtype, gn_partials=gn_partials)
     ws = workspace(lib.ml_conv2d_workspace_bytes(), x.device, "conv")
     name = _conv_kernel_name(dc.p, C.byref(d), 1, half=x.dtype == torch.float16)
     if PROFILE is not None:
@@ -506,6 +525,10 @@ def groupnorm_chunk_multi(problems):
         if pr.get("live") is not None:
             lv, period = pr["live"]
             d.live, d.live_period = lv.data_ptr(), int(period)
+        if pr.get("partials") is not None:         # (float64 [chunks * n, 2] written by the producing conv, n per chunk)
+            pt, npc = pr["partials"]
+            d.partials, d.n_partials = pt.data_ptr(), int(npc)
+            nbytes -= x.element_size() * x.numel() // 3       # (algorithmic bytes stay 1R + 1W; the pass that is gone was the 3rd)
         ws_bytes += (int(lib.ml_groupnorm_workspace_bytes(N, pr["groups"])) + 255) // 256 * 256
         nbytes += 2 * x.element_size() * x.numel()
         outs.append(out)

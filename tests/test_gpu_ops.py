@@ -455,3 +455,47 @@ def test_groupnorm_multi_equals_single_launches():
     hb = host(buf)
     assert np.all(hb[..., :32] == 7.0)
     np.testing.assert_array_equal(hb[..., 32:], np.maximum(single[1], 0.0))
+
+
+def test_groupnorm_statistics_from_the_conv_epilogue():
+    """ml_conv2d_desc.gn_partials / ml_gn_desc.partials: the head convs that feed a GroupNormalization
+    (engine/layers/detection.py:120-125, semantic.py:205-213) also write (sum, sum of squares) of every 128-row tile they
+    store; the GroupNorm apply pass adds a chunk's tiles in tile order instead of re-reading the tensor.  Same values as
+    conv -> two-pass GroupNorm to fp32 rounding of the statistics, and the oracle's; a launch too small for the rule is
+    refused loudly; the tower helper picks the form by itself."""
+    from masklab_hip import _lib, ops, packing
+    from masklab_hip.keras_like import Conv2D
+    from masklab_hip.layers.detection import _TowerMixin
+    from masklab_hip.normalization import GroupNormalization
+    B, H, W = 3, 128, 128                         # 384 tiles; chunk = 1024 pixels = 8 tiles
+    x = rnd(B, H, W, 128)
+    w, b = rnd(3, 3, 128, 128, scale=0.03), rnd(128)
+    gamma, beta = RNG.uniform(0.5, 1.5, 128).astype(np.float32), rnd(128)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    plain = ops.conv2d(dev(x), dc, act=_lib.ACT_RELU)
+    want = host(ops.groupnorm_chunk(plain, dev(gamma), dev(beta), 16))
+    part = torch.full((B * H * W // 128, 4, 2), float("nan"), dtype=torch.float64, device="cuda")
+    y = ops.conv2d(dev(x), dc, act=_lib.ACT_RELU, gn_partials=part)
+    np.testing.assert_array_equal(host(y), host(plain))                     # the conv's own output is untouched
+    yh = host(y).astype(np.float64).reshape(-1, 128 * 128)
+    np.testing.assert_allclose(host(part)[..., 0].sum(1), yh.sum(1), rtol=1e-7)      # (a float4 is folded in fp32 first)
+    np.testing.assert_allclose(host(part)[..., 1].sum(1), (yh * yh).sum(1), rtol=1e-6)
+    (got,) = ops.groupnorm_chunk_multi([dict(x=y, gamma=dev(gamma), beta=dev(beta), groups=16, out=y, partials=(part, 32))])
+    np.testing.assert_allclose(host(got), want, rtol=0, atol=2e-6)
+    ref = T.group_norm(T.relu(T.conv2d(x.astype(np.float64), w, b)), gamma, beta, 16)
+    np.testing.assert_allclose(host(got), ref, atol=3e-5)
+    with pytest.raises(RuntimeError, match="gn_partials"):                  # 64 tiles: the library would narrow / split this launch
+        ops.conv2d(dev(x[:1, :64]), dc, act=_lib.ACT_RELU, gn_partials=part)
+    # the tower helper: fused for the big level, the old two-pass / one-pass forms for the small ones, same results
+    conv, gn = Conv2D(128, (3, 3), activation='relu', padding='same', name="t/conv0"), GroupNormalization(16, name="t/gn0")
+    conv.build((None, None, None, 128)); gn.build((None, None, None, 128))
+    wd = {"t/conv0/kernel": w, "t/conv0/bias": b, "t/gn0/gamma": gamma, "t/gn0/beta": beta}
+    conv.load_weights(wd, torch.device("cuda:0")); gn.load_weights(wd, torch.device("cuda:0"))
+    xs = [rnd(B, 128, 128, 128), rnd(B, 64, 64, 128), rnd(B, 16, 16, 128)]
+    ops.PROFILE = []
+    outs = _TowerMixin._run_towers_multi([[conv, gn]] * 3, [dev(v) for v in xs])
+    recs, ops.PROFILE = ops.PROFILE, None
+    for v, o in zip(xs, outs):
+        np.testing.assert_allclose(host(o), T.group_norm(T.relu(T.conv2d(v.astype(np.float64), w, b)), gamma, beta, 16), atol=3e-5)
+    single = host(_TowerMixin._run_tower([conv, gn], dev(xs[0])))
+    np.testing.assert_array_equal(single, host(outs[0]))                    # one problem or five: the same tile sums

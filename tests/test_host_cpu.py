@@ -29,10 +29,11 @@ def test_conv_desc_struct_matches_header_layout():
     import ctypes
     from masklab_hip import _lib
     # 5 pointers, 28 int32, 1 int64, then (ABI 5) the `live` pointer + 2 int32
-    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 28 * 4 + 8 + 8 + 2 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 5 * 8 + 28 * 4 + 8 + 8 + 2 * 4 + 8
     assert _lib.ConvDesc.out_bstride.offset == 152 and _lib.ConvDesc.math.offset == 144
-    assert _lib.ConvDesc.live.offset == 160 and _lib.ConvDesc.live_period.offset == 168
-    assert ctypes.sizeof(_lib.GnDesc) == 4 * 8 + 8 + 8 * 4 + 8 + 2 * 4 and _lib.GnDesc.live.offset == 72
+    assert _lib.ConvDesc.live.offset == 160 and _lib.ConvDesc.live_period.offset == 168 and _lib.ConvDesc.gn_partials.offset == 176
+    assert ctypes.sizeof(_lib.GnDesc) == 4 * 8 + 8 + 8 * 4 + 8 + 2 * 4 + 8 + 2 * 4 and _lib.GnDesc.live.offset == 72
+    assert _lib.GnDesc.partials.offset == 88 and _lib.GnDesc.n_partials.offset == 96
     assert ctypes.sizeof(_lib.DeconvOutProblem) == 6 * 8 + 8 + 4 * 4 + 2 * 8 + 8 and _lib.DeconvOutProblem.live.offset == 88
 
 
