@@ -185,7 +185,7 @@ conv1x1_h256_kernel(const H256Args A) {
             const __amdgpu_buffer_rsrc_t ra_nx = more ? ra : ra_next;
             const __amdgpu_buffer_rsrc_t rb_nx = (more || next_panel < A.panels) ? rb : rsrc_at(A.wgt, 0, 0);
             const int soff = more ? (kc + 1) * ROWB : 0;
-            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0, 4, 8, ...
+            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0 .. 7
             f32x4 fa[2][4], fb[2][2];
             auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) {
                 const int slot16 = ((ks * 2 + h) ^ swz) * 16;
@@ -209,8 +209,8 @@ conv1x1_h256_kernel(const H256Args A) {
                 if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
                 const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
-                if constexpr ((idx & 3) == 0) {
-                    constexpr int p = idx >> 2;                         // piece 0..7
+                if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
+                    constexpr int p = idx;                              // piece 0..7
                     __builtin_amdgcn_sched_barrier(0);
                     if (do_dma) {
                         if constexpr (p < 4) lds_dma16(ra_nx, wrb + (64 * p + 8 * wave) * ROWB, a_voff[p], soff);
