@@ -437,3 +437,14 @@ def test_small_launches_pick_narrow_tiles():
     assert ntile([desc(1, 16, 16, 1024, 1024, k=3, group_step=32, tile=3)]) == 32    # grouped: packed for 32 already
     assert ntile([desc(1, 64, 64, 128, 48)]) == 32                     # cout <= 96 picks 32 / 64 by itself
     assert lib.ml_conv2d_launch_ntile(None, 1, 1) == 0
+
+
+def test_graft_entry_build_runs():
+    """`__graft_entry__.build()` is the driver's "does it build" check: make (up to date -> a no-op), import the package,
+    bind every symbol, header / library / binding ABI versions agree."""
+    import importlib
+    g = importlib.import_module("__graft_entry__")
+    g.build()
+    from masklab_hip import _lib
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "masklab_hip.h")).read()
+    assert f"#define ML_ABI_VERSION {_lib.ABI_VERSION} " in src
