@@ -136,20 +136,24 @@ def measured_traffic(kernel_label):
     gfx950 correction) -- ONLY if that pass recorded the hash of the current kernel sources; a stale pass gives None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2, false", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1, false",
-            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1, false"}.get(kernel_label)
+    # (a label covers every instantiation of that tile shape: the plain kernel and the one that also writes the
+    # GroupNorm partial sums -- their launches are averaged together, weighted by dispatches)
+    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2, 0,", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1, 0,",
+            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1, 0,"}.get(kernel_label)
     if not files or want is None:
         return None
     try:
         doc = json.load(open(files[-1]))
         if doc.get("source_sha256") != csrc_hash():
             return None
+        tot = n = 0
         for k, v in doc["kernels"].items():
             if want in k:
-                return round(v["hbm_bytes_per_launch"])
+                tot += v["hbm_bytes_per_launch"] * v["dispatches"]
+                n += v["dispatches"]
+        return round(tot / n) if n else None
     except Exception:
         return None
-    return None
 
 
 def build_model(backbone, device, seed=0, cls_scale=8.0):
