@@ -21,7 +21,15 @@
 // vmcnt(0) + barrier per chunk with the next chunk issued only one chunk ahead -- and a 128 KB tile drains at ~10 B/clk/CU
 // while the block's own MFMAs idle (one block per CU: nothing else to run).  Tried and measured no better: starting
 // blocks a quarter tile apart (s_sleep) so that epilogues overlap other blocks' K loops (132 -> 141 us on 1024->512,
-// 177 -> 172 on 512->1024 + residual); the next tile's chunk 1 issued before the stores with counted waits (kept: -2 %).
+// 177 -> 172 on 512->1024 + residual); the next tile's chunk 1 issued before the stores with counted waits (kept: -2 %);
+// a ring of four 32-deep chunks with three in flight and counted waits (scripts/experiments/
+// r03_h256_ring4_bk32_with_stamps.patch: 132 -> 140 us -- 64-byte row pieces are half cache lines, twice the requests).
+// In-kernel s_memtime stamps of that experiment: per 64-deep chunk a wave spends ~1 950 cycles in its 32 MFMAs (the
+// SIMD's matrix pipe is saturated while it runs: two waves x 32 x 32 cycles = 2 048) and ~1 150-1 400 waiting for the
+// next chunk, whatever the prefetch depth: the block takes in 64 KB per ~3 100 cycles = 21 B/clk/CU, against the
+// ~33 B/clk/CU an MI355X CU gets from L2 through LDS-direct loads when it does nothing else (MI355X_MICROARCH.md,
+// "Indexed rows": 66-73 GB/s per CU) -- and full-rate MFMA on a 256 x 256 tile NEEDS 32 B/clk/CU.  The kernel is bound
+// by the L2 -> LDS path; padding the row pitch off a power of two changes nothing (not an L2-channel effect).
 // Numerics: fp16 products are exact in fp32, fp32 accumulation in k order per output, bias / residual / clamp in fp32 --
 // the same arithmetic as conv1x1_pipe_kernel<_Float16> (which chains 64-deep chunks the same way).
 #include <type_traits>
