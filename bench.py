@@ -73,6 +73,8 @@ WORKLOADS = {
     "resnext101_full_b16_1280_f32": ("resnext101", 16, 1280, 1280),  # BASELINE configs[4] shape, fp32 path
     "resnext101_full_b16_1280_f16": ("resnext101", 16, 1280, 1280),  # BASELINE configs[4]: fp16 MFMA path, fp16 storage
     "resnext50_full_b8_1024_f16": ("resnext50", 8, 1024, 1024),      # configs[2] shape on the fp16 path
+    "resnext50_full_b8_1024_x3": ("resnext50", 8, 1024, 1024),       # configs[2], fp32 tensors, split-operand products (f32x3)
+    "resnext101_full_b16_1280_x3": ("resnext101", 16, 1280, 1280),   # configs[4] shape, fp32 tensors, f32x3
 }
 # which roofline binds each kernel class
 HBM_BOUND = ("groupnorm", "gconv3x3", "dwconv3x3", "maxpool", "resize", "preprocess", "detection", "cast", "trim",
@@ -362,6 +364,8 @@ def main():
     f16 = args.workload.endswith("_f16")
     if f16:
         ops.set_conv_math("f16s")      # BASELINE config 5: fp16 MFMA, fp16 tensors in the backbone body, fp32 heads
+    if args.workload.endswith("_x3"):
+        ops.set_conv_math("f32x3")     # fp32 tensors; every product = 3 f16 MFMAs on operands split into two halves
     cfg, model, weights, hot_weights = build_model(backbone, device)
     images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
     if args.graph:
@@ -459,6 +463,8 @@ def main():
             elif k.startswith(("conv_mfma", "conv1x1", "deconv2x2")):
                 # the dense MFMA peak of the type the kernel multiplies in: "_f16" / "_h" launches run fp16 MFMAs
                 peak = PEAK_F16_MFMA_TFLOPS if (k.endswith(("_f16", "_h")) or f16) else PEAK_F32_MFMA_TFLOPS
+                if k.endswith("_x3"):          # three f16 MFMA flops per algorithmic flop
+                    peak = round(PEAK_F16_MFMA_TFLOPS / 3.0, 1)
                 e["bound"], e["mfma_frac"], e["mfma_peak"] = "mfma", round(e["tflops"] / peak, 4), peak
                 e["hbm_frac"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
                 if e["hbm_frac"] > e["mfma_frac"]:
@@ -475,12 +481,16 @@ def main():
         mp = measured_peaks()
         if dom.startswith("conv_mfma") and not (f16 or dom.endswith("_h")):
             ach = d["gflop"] / d["ms"]          # GFLOP/ms = TFLOP/s
-            roofline = dict({"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic},
-                            **common)
+            # f32x3: `achieved` counts ALGORITHMIC flops; the matrix pipe issues three f16 MFMA flops for each
+            x3 = dom.endswith("_x3")
+            peak = round(PEAK_F16_MFMA_TFLOPS / 3.0, 1) if x3 else PEAK_F32_MFMA_TFLOPS
+            roofline = dict({"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic}, **common)
+            if x3:
+                roofline["peak_note"] = "dense f16 MFMA peak / 3 (three f16 MFMAs per fp32-grade product)"
             if mp:
-                roofline.update(peak_measured=mp["mfma_f32_TFLOPs"], frac_of_measured=round(ach / mp["mfma_f32_TFLOPs"], 4),
-                                peak_measured_source=mp["source"])
+                pm = round(mp["mfma_f16_TFLOPs"] / 3.0, 1) if x3 else mp["mfma_f32_TFLOPs"]
+                roofline.update(peak_measured=pm, frac_of_measured=round(ach / pm, 4), peak_measured_source=mp["source"])
         else:
             # HBM-bound kernels -- including the dense conv on the fp16 path: at fp16 the ridge is ~300 flop/B,
             # far above the 1x1 convs' arithmetic intensity, so moving the operands binds, not the matrix cores

@@ -36,7 +36,7 @@ extern "C" {
 #define ML_E_NOGPU  (-3)   /* no gfx950 device visible                        */
 
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
-enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2 };
+enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
 
 #define ML_ABI_VERSION 5              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
@@ -92,7 +92,16 @@ typedef struct ml_conv2d_desc {
                                1x1 stride-1 problems with cout % 128 == 0 and span % 64 == 0 run on the
                                persistent kernel (conv1x1_pipe.hip: half output, optional half residual);
                                every other shape on the generic kernel (no residual; output half or fp32
-                               by `out_f16`)                                                     */
+                               by `out_f16`);
+                               ML_MATH_F32X3: fp32 tensors, fp32-grade arithmetic on the f16 matrix pipe: each
+                               operand x = hi + 2^-11 lo (two halves), each product hi hi + 2^-11 (hi lo + lo hi)
+                               with fp32 accumulation (operands to 2^-22 relative for 2^-14 <= |x| < 65520, 2^-36
+                               absolute below; the dropped term is <= 2^-22 |a b|).
+                               Activations are split inside the kernel (|x| < 65520, else Inf / NaN); `wgt` points to
+                               weights split BEFOREHAND: the fp32 packing with every 32-float chunk of a row
+                               replaced, in place, by 32 halves hi(w) followed by 32 halves 2^11 (w - hi(w))
+                               (same bytes, same strides; masklab_hip/ops.py DeviceConv.wgt_x3).  Generic
+                               kernel only (every shape, residual, split-K, gn_partials as ML_MATH_F32)   */
     int32_t out_f16;        /* 1 = `out` is IEEE half: ML_MATH_F16 (the stem feeding an fp16-storage body)
                                and ML_MATH_F16S on the generic kernel (0 there = fp32 `out`: the prediction
                                tensors); dense fast epilogue only (no residual / shuffle2x2 / out_bstride /

@@ -146,6 +146,33 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
     return ok;
 }
 
+// ML_MATH_F32X3: 8 fp32 values -> 8 halves `hi` (round to nearest: v_cvt_pk_f16_f32) and 8 halves `lo` = (x - hi) * 2^11,
+// rounded to nearest.  x - hi is exact in fp32 (at most 13 significant bits), |lo| <= |x|, and the scaling keeps lo a NORMAL
+// half wherever x is one, so |x - (hi + 2^-11 lo)| <= 2^-22 |x| for 2^-14 <= |x| < 65520 (smaller: 2^-36; beyond: hi overflows, the result is
+// Inf / NaN -- loud, as in the fp16-storage mode).  16 VALU instructions: 4 packed multiplies (x * 2^11), 4 packed converts,
+// 8 v_fma_mix (f16 hi * -2^11 + the scaled x, result stored as f16).
+__device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, const float neg_scale, f16x8 &hi, f16x8 &lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x4 s0 = x0 * 2048.f, s1 = x1 * 2048.f;
+    unsigned hw[4], lw[4];
+    hw[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[0], x0[1]}, f16x2));
+    hw[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[2], x0[3]}, f16x2));
+    hw[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[0], x1[1]}, f16x2));
+    hw[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[2], x1[3]}, f16x2));
+    const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "+v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i + 1]));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 H = {hw[0], hw[1], hw[2], hw[3]}, L = {lw[0], lw[1], lw[2], lw[3]};
+    hi = __builtin_bit_cast(f16x8, H);
+    lo = __builtin_bit_cast(f16x8, L);
+}
+
 // F16 = true: the "fp16 MFMA path" (BASELINE config 5): activations and weights stay fp32 in HBM, are
 // rounded to fp16 (RNE) on their way into LDS, and the contraction runs on v_mfma_f32_32x32x16_f16 with
 // fp32 accumulation -- 2 instructions of 32 cycles per 32-deep chunk and tile pair instead of 16 of 64.
@@ -155,16 +182,23 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
 // prefetch pieces are the f32 code with the element size changed; a chunk is 4 k-steps of v_mfma_f32_32x32x16_f16
 // (one ds_read_b128 = the 8 halves a lane feeds).  Accumulation, bias and activation are fp32; the output is half
 // (`out_f16`, one rounding at the store) or fp32 (the prediction tensors detect.hip reads).
+// MATH = ML_MATH_F32X3: fp32 tensors, fp32-grade products on the f16 matrix pipe.  Every operand is written as
+// x = hi + 2^-11 lo (two halves, 22 bits, split_hi_lo above; the weights arrive already split, masklab_hip.h) and a product as
+// hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b) -- three v_mfma_f32_32x32x16_f16 per 16-deep step into TWO fp32 accumulator sets
+// (the cross terms keep their own, folded in once at the end).  Each f16 x f16 product is exact in fp32; what is dropped is
+// lo_a lo_b <= 2^-22 |a b|, below the rounding of the fp32 accumulation itself.  3 x 8 passes against 8 x 16 for the same
+// 16-deep step on v_mfma_f32_32x32x2_f32: 5.3 x the fp32 matrix rate.  Staging, addressing, epilogue: the f32 code.
 // GNS = the conv -> (activation) -> GroupNormalization pairs of the heads (engine/layers/detection.py:120-125,
 // semantic.py:205-213): the epilogue also sums its tile's stored values (sum, sum of squares: a float4 folded in fp32, then
 // fp64 -- the same folding as gn_stats_kernel) and writes one pair per WAVE (4 per tile) to `gn_partials`; the GroupNorm
 // apply pass adds the pairs of a chunk's tiles in order instead of re-reading the tensor (csrc/groupnorm.hip).  A separate
 // instantiation: the kernel every other conv runs is untouched.
 template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false>
-__global__ void __launch_bounds__(256, GNS ? 2 : 1)      // (GNS: keep two blocks per CU -- 262 registers otherwise)
+__global__ void __launch_bounds__(256, (GNS || MATH == ML_MATH_F32X3) ? 2 : 1)      // (GNS: keep two blocks per CU -- 262 registers otherwise)
 conv_mfma_kernel(const MultiArgs args) {
     constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
     constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
+    constexpr bool X3 = MATH == ML_MATH_F32X3;     // fp32 tensors, staged like ML_MATH_F32; split products on the f16 MFMA
     constexpr int ES = HS ? 2 : 4;                 // bytes per tensor element
     constexpr int KC = HS ? 64 : 32;               // elements per K chunk
     constexpr int BM = WAVES_M * TM * 32;
@@ -283,7 +317,8 @@ conv_mfma_kernel(const MultiArgs args) {
     const bool direct = (P.splits == 1);
     const bool vec_ok = out_vec_ok(p) && (n + 4 <= p.cout);
     f32x4 res[E_ROWS];
-    const bool pre_res = direct && p.residual && vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID;
+    // (X3: two accumulator sets at two blocks per CU leave no room for 32 prefetched registers: the residual is read in the epilogue)
+    const bool pre_res = !X3 && direct && p.residual && vec_ok && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID;
     if (pre_res) {
 #pragma unroll
         for (int i = 0; i < E_ROWS; ++i) {
@@ -392,6 +427,7 @@ conv_mfma_kernel(const MultiArgs args) {
     // to ONE output column, so it costs one scalar load per tile column block.
     const bool fast_blk = direct && (out_vec_ok(p) || p.out_f16) && !p.shuffle2x2 && p.act != ML_ACT_SIGMOID && (p.cout % 4 == 0);
     f32x16 acc[TM][TN];
+    f32x16 accx[X3 ? TM : 1][X3 ? TN : 1];             // X3: the two cross terms, in units of 2^-11
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int col = n0 + wn * TN * 32 + ni * 32 + r;
@@ -399,7 +435,10 @@ conv_mfma_kernel(const MultiArgs args) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b0;
+            for (int e = 0; e < 16; ++e) {
+                acc[mi][ni][e] = b0;
+                if constexpr (X3) accx[mi][ni][e] = 0.f;
+            }
     }
 
     const int a_off = F16 ? (wm * TM * 32 + r) * LDS_LD_H + h * 8 : (wm * TM * 32 + r) * LDS_LD;
@@ -456,6 +495,51 @@ conv_mfma_kernel(const MultiArgs args) {
             }
 #pragma unroll
             for (int q = 0; q < NPIECE; ++q)                 // what did not fit between the MFMAs
+                if (q >= placed) {
+                    if (q < A_LD) piece_a(q);
+                    else if (q < A_LD + B_LD) piece_b(q - A_LD, kc_next);
+                    else piece_end();
+                }
+        } else if constexpr (X3) {
+            // lane (r, h) feeds A[row r][k = 16 ks + 8 h + j], j = 0..7: fp32 k-groups 4 ks + 2 h and + 1 of its row, split
+            // here; the B row of a chunk is 32 hi halves (k-groups 0..3) then 32 scaled lo halves (k-groups 4..7)
+            const float neg_scale = -2048.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const float *row = base + a_off + mi * 32 * LDS_LD;
+                    split_hi_lo(*reinterpret_cast<const f32x4 *>(row + (((ks * 4 + 2 * h) ^ swz) * 4)),
+                                *reinterpret_cast<const f32x4 *>(row + (((ks * 4 + 2 * h + 1) ^ swz) * 4)), neg_scale, ah[mi], al[mi]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const float *row = base + b_off + ni * 32 * LDS_LD;
+                    bh[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(row + (((ks * 2 + h) ^ swz) * 4)));
+                    bl[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(row + (((4 + ks * 2 + h) ^ swz) * 4)));
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni) {
+                            if (t == 0) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                            else if (t == 1) accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], accx[mi][ni], 0, 0, 0);
+                            else accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], accx[mi][ni], 0, 0, 0);
+                            if (placed < NPIECE) {               // one prefetch piece per MFMA
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (placed < A_LD) piece_a(placed);
+                                else if (placed < A_LD + B_LD) piece_b(placed - A_LD, kc_next);
+                                else piece_end();
+                                ++placed;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+            }
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)                 // what did not fit between the MFMAs (narrow tiles)
                 if (q >= placed) {
                     if (q < A_LD) piece_a(q);
                     else if (q < A_LD + B_LD) piece_b(q - A_LD, kc_next);
@@ -541,7 +625,9 @@ conv_mfma_kernel(const MultiArgs args) {
             for (int e = 0; e < 16; ++e) {
                 const int row = wm * TM * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int col = wn * TN * 32 + ni * 32 + r;
-                lds[row * C_LD + col] = acc[mi][ni][e];
+                float v = acc[mi][ni][e];
+                if constexpr (X3) v = fmaf(accx[mi][ni][e], 0x1p-11f, v);
+                lds[row * C_LD + col] = v;
             }
     __syncthreads();
 
@@ -988,8 +1074,7 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     if (n_in == 1 && (descs_in[0].tile == 0 || descs_in[0].tile == 4 || descs_in[0].tile == 5)) {
         const int rc0 = validate(descs_in[0], false);
         if (rc0 != ML_OK) return rc0;
-        ML_REQUIRE(descs_in[0].math == ML_MATH_F32 || descs_in[0].math == ML_MATH_F16 || descs_in[0].math == ML_MATH_F16S,
-                   "conv2d: unknown math mode %d", descs_in[0].math);
+        ML_REQUIRE(descs_in[0].math >= ML_MATH_F32 && descs_in[0].math <= ML_MATH_F32X3, "conv2d: unknown math mode %d", descs_in[0].math);
         int took = 0;
         const bool half = descs_in[0].math == ML_MATH_F16S;
         if (half && h256_preferred(descs_in[0])) {
@@ -1022,8 +1107,7 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
                    "conv2d: the fp16-storage form of the generic kernel takes no residual (only the persistent 1x1 kernel does: "
                    "stride 1, cout %% 128 == 0, span %% 64 == 0, half output)");
     }
-    ML_REQUIRE(descs[0].math == ML_MATH_F32 || descs[0].math == ML_MATH_F16 || descs[0].math == ML_MATH_F16S,
-               "conv2d: unknown math mode %d", descs[0].math);
+    ML_REQUIRE(descs[0].math >= ML_MATH_F32 && descs[0].math <= ML_MATH_F32X3, "conv2d: unknown math mode %d", descs[0].math);
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     long long ref_tiles = -1;
@@ -1044,8 +1128,15 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     }
     bool any_gns = false;
     for (int i = 0; i < n; ++i) any_gns = any_gns || descs[i].gn_partials != nullptr;
-    ML_REQUIRE(!any_gns || (t == 1 && descs[0].math == ML_MATH_F32),
-               "conv2d: gn_partials needs the fp32 128 x 128 kernel (a launch of >= 257 tiles)");
+    ML_REQUIRE(!any_gns || t == 1, "conv2d: gn_partials needs the fp32 128 x 128 kernel (a launch of >= 257 tiles)");
+    if (descs[0].math == ML_MATH_F32X3) {
+        if (any_gns) return launch_multi<2, 2, 2, 2, ML_MATH_F32X3, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        switch (t) {
+            case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            default: return launch_multi<4, 1, 1, 1, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        }
+    }
     if (any_gns) return launch_multi<2, 2, 2, 2, ML_MATH_F32, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
     switch (t) {
         case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F32>(descs, n, workspace, workspace_bytes, s, ref_tiles);

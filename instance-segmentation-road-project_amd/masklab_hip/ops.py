@@ -48,9 +48,11 @@ class _Prof:
 # accumulation, statistics, bias and activation are fp32 with one rounding at the store); only what detect.hip reads
 # and what the model returns -- cls_pred, loc_pred, roi_boxes, roi_masks, seg_pred -- is fp32.  Kernels follow the
 # dtype of the tensor they are given: an fp32 tensor in this mode (MobileNet's body) runs like "f16".
+# "f32x3" = fp32 tensors and fp32-grade arithmetic on the f16 matrix pipe (ML_MATH_F32X3): every operand is split into
+# two halves (22 bits), every product is three f16 MFMAs with fp32 accumulation; 1x1 convs run on the generic kernel.
 # Process-wide switch, read when a conv is launched; set it through set_conv_math().
 CONV_MATH = "f32"
-_MATH_CODE = {"f32": 0, "f16": 1, "f16s": 1}        # per-launch code of fp32-tensor convs; half tensors select ML_MATH_F16S
+_MATH_CODE = {"f32": 0, "f16": 1, "f16s": 1, "f32x3": 3}   # per-launch code of fp32-tensor convs; half tensors select ML_MATH_F16S
 
 
 def set_conv_math(mode):
@@ -62,7 +64,8 @@ def set_conv_math(mode):
 
 def dtype_label():
     """The arithmetic type the dense-conv path computes in (bench.py's `dtype`)."""
-    return {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate, f32 tensors",
+    return {"f32": "f32", "f32x3": "f32 tensors, products as 3 x f16 MFMA on split operands (22-bit), f32 accumulate",
+            "f16": "f16 MFMA operands, f32 accumulate, f32 tensors",
             "f16s": "f16 MFMA, f32 accumulate, f16 tensors in backbone body and heads (f32 predictions)"}[CONV_MATH]
 
 
@@ -109,6 +112,23 @@ class DeviceConv:
         self.wgt = torch.from_numpy(np.ascontiguousarray(packed.wgt)).to(device)
         self.bias = None if packed.bias is None else torch.from_numpy(packed.bias).to(device)
         self._wgt_h = None
+        self._wgt_x3 = None
+
+    @property
+    def wgt_x3(self):
+        """The packed weights split for ML_MATH_F32X3 (include/masklab_hip.h): every 32-float chunk of a row becomes 32
+        halves hi(w) followed by 32 halves 2^11 (w - hi(w)) -- same bytes, same strides; made on first use."""
+        if self._wgt_x3 is None:
+            w = np.ascontiguousarray(self.p.wgt, dtype=np.float32)
+            rows, ktot = w.shape
+            if ktot % 32:
+                raise RuntimeError("f32x3: the packed row length must be a multiple of 32 floats")
+            c = w.reshape(rows, ktot // 32, 32)
+            hi = c.astype(np.float16)
+            lo = ((c - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+            both = np.ascontiguousarray(np.concatenate([hi, lo], axis=2))            # [rows, chunks, 64] halves
+            self._wgt_x3 = torch.from_numpy(both.view(np.float32).reshape(rows, ktot)).to(self.wgt.device)
+        return self._wgt_x3
 
     @property
     def span_pad_h(self):
@@ -185,7 +205,8 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
         ret = out
         d.out = out.data_ptr()
         d.out_cstride, d.out_coff, d.out_bstride = out.shape[3], out_coff, 0
-    d.in_, d.wgt, d.bias = x.data_ptr(), (dc.wgt_h if half_in else dc.wgt).data_ptr(), \
+    x3 = CONV_MATH == "f32x3" and not half_in
+    d.in_, d.wgt, d.bias = x.data_ptr(), (dc.wgt_h if half_in else (dc.wgt_x3 if x3 else dc.wgt)).data_ptr(), \
         (dc.bias.data_ptr() if dc.bias is not None else None)
     if residual is not None:
         _require_dev(residual, "residual")
@@ -231,7 +252,7 @@ def _conv_kernel_name(p, descs=None, n=1, half=False):
     if not bn:
         bn = lib.ml_conv2d_ntile(p.cout, p.tile)
     return "conv_mfma_128x%d%s%s" % (bn, "_grouped" if p.group_cin_step else "",
-                                     "_h" if half else ("_f16" if CONV_MATH != "f32" else ""))
+                                     "_h" if half else {"f32": "", "f32x3": "_x3"}.get(CONV_MATH, "_f16"))
 
 
 def gn_fusable(out_shape, C_out, groups, dc, launch_tiles, dtype):
@@ -242,7 +263,7 @@ def gn_fusable(out_shape, C_out, groups, dc, launch_tiles, dtype):
     B, Ho, Wo = out_shape
     hw = Ho * Wo
     p = dc.p
-    ok = (CONV_MATH == "f32" and dtype == torch.float32 and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
+    ok = (CONV_MATH in ("f32", "f32x3") and dtype == torch.float32 and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
           not p.shuffle2x2 and not p.group_cin_step and hw % 128 == 0 and hw % groups == 0 and (hw // groups) % 128 == 0 and
           launch_tiles >= 257)
     return 4 * ((hw // groups) // 128) if ok else 0

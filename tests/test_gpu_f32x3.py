@@ -1,0 +1,186 @@
+"""ML_MATH_F32X3 -- fp32 tensors, every product of the dense convs as three f16 MFMAs on operands split into two halves
+(x = hi + 2^-11 lo, 22 bits; fp32 accumulation) -- held to the bars of the fp32 path, unchanged: the end-to-end tests of
+tests/test_gpu_model.py run again under this mode (indices bit-exact, in order; floats within 1e-3 of the oracle), the op
+tests of tests/test_gpu_ops.py are parametrised over it (same absolute tolerances), and here: its error against an fp64
+convolution of the same fp32 operands is not larger than that of the exact-product fp32 MFMA path, at three input scales;
+the documented operand range; which kernels a forward in this mode runs on.  -m gpu."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import tfops as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name + "_under_f32x3", os.path.join(HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _mode():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from masklab_hip import _lib, ops
+    _lib.check(_lib.load().ml_device_check(), "ml_device_check")
+    ops.set_conv_math("f32x3")
+    yield
+    ops.set_conv_math("f32")
+
+
+@pytest.fixture(scope="module")
+def M():
+    return _load("test_gpu_model")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------ the model-level bars of the fp32 path, unchanged
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50", "resnext101"])
+def test_full_forward_matches_oracle(M, bt):
+    M.test_full_forward_matches_oracle(bt)
+
+
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50"])
+def test_full_forward_with_detections(M, bt):
+    M.test_full_forward_with_detections(bt)
+
+
+@pytest.mark.parametrize("case", ["forward_mobilenet_128", "forward_resnext50_128"])
+def test_forward_matches_committed_golden(M, case, golden_dir):
+    M.test_forward_matches_committed_golden(case, golden_dir)
+
+
+@pytest.mark.parametrize("bt,size", [("resnext50", 1024), ("resnext101", 1280)])
+def test_headline_size_indices_bit_exact(M, bt, size):
+    M.test_headline_size_indices_bit_exact(bt, size)
+
+
+def test_batch_sharding_equals_full_batch(M):
+    M.test_batch_sharding_equals_full_batch()
+    M.test_batch_sharding_where_the_split_k_decision_differs()
+
+
+@pytest.mark.parametrize("bt", ["mobilenet", "resnext50"])
+def test_hipgraph_replay_equals_eager(M, bt):
+    M.test_hipgraph_replay_equals_eager(bt)
+
+
+@pytest.mark.parametrize("bt,shape,thr", [("mobilenet", (3, 128, 256, 3), 0.5), ("resnext50", (2, 192, 160, 3), 0.5)])
+def test_fixed_capacity_stage2_matches_oracle(M, bt, shape, thr):
+    M.test_fixed_capacity_stage2_matches_oracle(bt, shape, thr)
+
+
+def test_which_kernels_a_forward_runs_on(M):
+    """Every dense conv of the forward runs the split-operand kernel (no silent fp32 launches, no pipelined-fp32 1x1);
+    grouped 3x3, depthwise and the fused mask-head tail keep their fp32 kernels."""
+    from masklab_hip import ops
+    cfg, model, w = M._build("resnext50", seed=5, hot_cls=True)
+    images = np.random.default_rng(99).integers(0, 256, (2, 128, 256, 3), dtype=np.uint8)
+    model.predict(images)
+    ops.PROFILE = []
+    model.predict(images)
+    names, ops.PROFILE = sorted({r["kernel"] for r in ops.PROFILE}), None
+    conv = [n for n in names if n.startswith(("conv_mfma", "conv1x1"))]
+    assert conv and all(n.endswith("_x3") for n in conv), names
+    assert any(n.startswith("gconv3x3") for n in names)
+
+
+# ------------------------------------------------------------------ not a reduced precision: error against fp64
+@pytest.mark.parametrize("k,cin,cout,hw,stride,res,scale", [
+    (3, 64, 96, (19, 23), 1, False, 1.0), (1, 256, 128, (24, 24), 1, True, 1.0), (3, 256, 256, (32, 32), 1, False, 1.0),
+    (3, 128, 128, (33, 33), 2, False, 1.0), (1, 2048, 256, (16, 16), 1, False, 1.0),
+    (3, 256, 256, (32, 32), 1, False, 1e-3), (3, 256, 256, (32, 32), 1, False, 1e3), (3, 256, 256, (16, 16), 1, False, 1e-6)])
+def test_error_against_fp64_not_above_the_exact_fp32_product_path(k, cin, cout, hw, stride, res, scale):
+    """Same fp32 operands through both modes, compared with the oracle's fp64 convolution.  The split drops at most
+    2^-22 |a b| per product; the fp32 accumulation (both modes) rounds at 2^-24 of the running sum per step, which
+    dominates -- measured, the split-operand path is the CLOSER one (a 16-deep MFMA step adds 16 exact products before it
+    rounds; the fp32 instruction rounds after every 2).  Asserted: rms and max error <= 1.05 x the fp32 path's, for
+    operands in the normal range of a half (2^-14 <= |x| < 65520: inputs x 1e-3, x 1, x 1e3); the last case puts every
+    activation BELOW it and checks the documented absolute floor instead."""
+    from masklab_hip import _lib, ops, packing
+    rng = np.random.default_rng(7)
+    x = (rng.normal(size=(2, hw[0], hw[1], cin)) * scale).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = (rng.normal(size=(cout,)) * scale).astype(np.float32)
+    ref = T.conv2d(x.astype(np.float64), w, b, stride, "same")
+    r = None
+    if res:
+        r = (rng.normal(size=ref.shape) * scale).astype(np.float32)
+        ref = ref + r
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    err = {}
+    for mode in ("f32", "f32x3"):
+        ops.set_conv_math(mode)
+        got = host(ops.conv2d(dev(x), dc, stride=stride, padding="same", residual=None if r is None else dev(r)))
+        e = got.astype(np.float64) - ref
+        err[mode] = (float(np.sqrt((e * e).mean())), float(np.abs(e).max()))
+    ops.set_conv_math("f32x3")
+    if scale < 2.0 ** -14:
+        # activations below the smallest normal half: their low halves are subnormals, 2^-36 ABSOLUTE per activation
+        # (negligible beside any product of normal-range operands, but no longer relative) -- the documented floor
+        floor = 2.0 ** -36 * float(np.abs(w.astype(np.float64)).sum((0, 1, 2)).max())
+        assert err["f32x3"][1] <= 1.05 * err["f32"][1] + floor, (err, floor)
+        return
+    assert err["f32x3"][0] <= 1.05 * err["f32"][0], err
+    assert err["f32x3"][1] <= 1.05 * err["f32"][1], err
+    assert err["f32x3"][1] <= 1e-6 * float(np.abs(ref).max()), err
+
+
+def test_operand_range_and_special_values():
+    """The split keeps 22 bits wherever |x| < 65520 (include/masklab_hip.h): powers of two, values with all 24 bits set,
+    tiny values (below 2^-14 the low half is a subnormal: 2^-36 absolute), zeros and mixed signs against fp64, one
+    input channel at a time so that a product's error is not averaged away."""
+    from masklab_hip import ops, packing
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.1415927, -2.7182817, 32767.998, -32000.123,
+                     1e-3, -1.2345678e-4, 6.1e-5, 5.9e-8, 2.0 ** -20 * 1.9999999, 1024.0009765625, 255.99998, 1e-7, -3e-8, 12345.678,
+                     0.1, 0.2, 0.3, 0.7, 1.9999999, 0.99999994, 7.0, 65.0, 4097.0, 65000.5, 2.0 ** -14, 2.0 ** -14 * 1.0000001],
+                    np.float32)
+    cin = 32
+    assert vals.size == cin
+    x = np.zeros((1, 8, 16, cin), np.float32)                     # pixel p carries vals[p % 32] in channel p % 32 only
+    for p in range(128):
+        x[0, p // 16, p % 16, p % cin] = vals[p % cin]
+    wv = np.array([1.0, -1.0, 0.33333334, 1.0 + 2.0 ** -23, 3.0e-3, -7.7777777, 1.9999999, 2.0 ** -12], np.float32)
+    w = np.zeros((1, 1, cin, 32), np.float32)
+    for o in range(32):
+        w[0, 0, :, o] = wv[o % 8] * (1.0 + o // 8 * 2.0 ** -20)
+    ref = T.conv2d(x.astype(np.float64), w, None, 1, "valid")
+    got = host(ops.conv2d(dev(x), ops.DeviceConv(packing.pack_dense(w, None), "cuda"), padding="valid")).astype(np.float64)
+    assert np.isfinite(got).all()
+    # one product a b per output: |error| <= (3 x 2^-22 + 2^-24) |a b| -- two split operands, the dropped lo x lo term, the
+    # fp32 store -- plus, for operands below 2^-14 (whose low half is a subnormal), 2^-36 absolute per operand
+    a = np.abs(x.reshape(128, cin).astype(np.float64))                                   # [pixel, channel]
+    bw = np.abs(w[0, 0].astype(np.float64))                                             # [channel, out]
+    bound = (np.abs(ref.reshape(128, 32)) * (3 * 2.0 ** -22 + 2.0 ** -24) +
+             2.0 ** -36 * ((a > 0) @ bw + a @ (bw > 0)))
+    err = np.abs(got.reshape(128, 32) - ref.reshape(128, 32))
+    assert np.all(err <= bound), float(np.max(err / np.maximum(bound, 1e-300)))
+
+
+def test_weights_are_split_once_on_the_host():
+    """DeviceConv.wgt_x3: same bytes and strides as the fp32 packing; hi + 2^-11 lo reproduces every weight to 2^-22."""
+    from masklab_hip import ops, packing
+    rng = np.random.default_rng(3)
+    w = (rng.normal(size=(3, 3, 40, 72)) * 0.05).astype(np.float32)
+    dc = ops.DeviceConv(packing.pack_dense(w, None), "cuda")
+    a, s = host(dc.wgt), host(dc.wgt_x3)
+    assert a.shape == s.shape and a.dtype == s.dtype == np.float32
+    h = s.view(np.float16).reshape(a.shape[0], -1, 64).astype(np.float64)
+    back = (h[..., :32] + h[..., 32:] * 2.0 ** -11).reshape(a.shape)
+    assert np.all(np.abs(back - a) <= np.abs(a) * 2.0 ** -22)

@@ -39,6 +39,16 @@ def _conv(packed, x, **kw):
     return ops.conv2d(dev(x), ops.DeviceConv(packed, "cuda"), **kw)
 
 
+@pytest.fixture(params=["f32", "f32x3"])
+def conv_math(request):
+    """The dense-conv tests run twice on the same tolerances: exact fp32 products (ML_MATH_F32) and the split-operand
+    products on the f16 matrix pipe (ML_MATH_F32X3: fp32 tensors, 22-bit operands, fp32 accumulation)."""
+    from masklab_hip import ops
+    ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math("f32")
+
+
 # ------------------------------------------------------------------ conv family
 @pytest.mark.parametrize("k,cin,cout,stride,padding,dil,act,hw", [
     (1, 64, 256, 1, "valid", 1, "relu", (40, 24)),        # backbone 1x1, N tile 128
@@ -55,7 +65,7 @@ def _conv(packed, x, **kw):
     (1, 8, 128, 1, "valid", 1, "sigmoid", (1, 1)),        # SE dense (cin 8 < 32)
     (3, 32, 96, 1, "same", 3, "relu6", (12, 12)),         # dilation 3
 ])
-def test_conv2d_dense(k, cin, cout, stride, padding, dil, act, hw):
+def test_conv2d_dense(k, cin, cout, stride, padding, dil, act, hw, conv_math):
     from masklab_hip import _lib, packing
     B = 2
     x = rnd(B, hw[0], hw[1], cin)
@@ -129,7 +139,7 @@ def test_conv1x1_pipelined_kernel_is_the_default_for_short_k():
         ops.conv2d(dev(rnd(1, 8, 8, 64)), ops.DeviceConv(packing.pack_dense(rnd(3, 3, 64, 128), None, tile=4), "cuda"))
 
 
-def test_conv2d_residual_and_concat_slice():
+def test_conv2d_residual_and_concat_slice(conv_math):
     from masklab_hip import _lib, ops, packing
     x, res = rnd(2, 12, 12, 64), rnd(2, 12, 12, 96)
     w, b = rnd(1, 1, 64, 96, scale=0.1), rnd(96)
@@ -144,7 +154,7 @@ def test_conv2d_residual_and_concat_slice():
     assert np.all(o[..., :32] == 7.0) and np.all(o[..., 128:] == 7.0)
 
 
-def test_conv2d_out_view_concatenated_prediction():
+def test_conv2d_out_view_concatenated_prediction(conv_math):
     from masklab_hip import ops, packing
     B, nc, pri = 3, 5, 15
     levels = [(8, 8), (4, 4)]
@@ -163,7 +173,7 @@ def test_conv2d_out_view_concatenated_prediction():
 
 @pytest.mark.parametrize("k,stride,padding,cout,act", [(7, 2, ((3, 3), (3, 3)), 64, "relu"),
                                                        (3, 2, ((0, 1), (0, 1)), 32, "relu6")])
-def test_conv2d_rowspan_stem(k, stride, padding, cout, act):
+def test_conv2d_rowspan_stem(k, stride, padding, cout, act, conv_math):
     from masklab_hip import _lib, packing
     img = rnd(2, 64, 48, 3)
     x4 = np.zeros((2, 64, 48, 4), np.float32)
@@ -175,7 +185,7 @@ def test_conv2d_rowspan_stem(k, stride, padding, cout, act):
 
 
 @pytest.mark.parametrize("c,stride,filters", [(4, 1, 128), (8, 2, 256), (16, 1, 512), (32, 2, 1024)])
-def test_conv2d_grouped_resnext(c, stride, filters):
+def test_conv2d_grouped_resnext(c, stride, filters, conv_math):
     from masklab_hip import _lib, packing
     groups = filters // c
     x = rnd(2, 10, 12, filters)
@@ -202,7 +212,7 @@ def test_gconv3x3_mfma4(c, stride, filters, hw):
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
-def test_conv2d_transpose2x2():
+def test_conv2d_transpose2x2(conv_math):
     from masklab_hip import _lib, packing
     x = rnd(5, 14, 14, 128)
     w, b = rnd(2, 2, 128, 128, scale=0.05), rnd(128)
@@ -262,7 +272,7 @@ def test_deconv2x2_out1x1_rejects_bad_shapes():
 @pytest.mark.parametrize("k,cin,cout,hw,stride", [(3, 2048, 128, (6, 6), 2), (1, 2048, 128, (16, 16), 1),
                                                   (1, 2048, 128, (1, 1), 1), (3, 128, 128, (8, 8), 1),
                                                   (1, 640, 128, (32, 32), 1), (3, 256, 75, (4, 4), 1)])
-def test_conv2d_split_k_small_m(k, cin, cout, hw, stride):
+def test_conv2d_split_k_small_m(k, cin, cout, hw, stride, conv_math):
     """few output tiles + long K => the split-K path (partials in the workspace, fixed-order reduce)."""
     from masklab_hip import _lib, packing
     x = rnd(2, hw[0], hw[1], cin)
@@ -283,7 +293,7 @@ def test_conv2d_split_k_small_m(k, cin, cout, hw, stride):
     np.testing.assert_array_equal(got1, got2)        # deterministic reduction order
 
 
-def test_conv2d_multi_problem_launch():
+def test_conv2d_multi_problem_launch(conv_math):
     """the same conv shape at 5 pyramid levels + a strided-view destination, one launch"""
     from masklab_hip import _lib, ops, packing
     B, nc, pri = 2, 5, 15
@@ -457,7 +467,7 @@ def test_groupnorm_multi_equals_single_launches():
     np.testing.assert_array_equal(hb[..., 32:], np.maximum(single[1], 0.0))
 
 
-def test_groupnorm_statistics_from_the_conv_epilogue():
+def test_groupnorm_statistics_from_the_conv_epilogue(conv_math):
     """ml_conv2d_desc.gn_partials / ml_gn_desc.partials: the head convs that feed a GroupNormalization
     (engine/layers/detection.py:120-125, semantic.py:205-213) also write (sum, sum of squares) of every 128-row tile they
     store; the GroupNorm apply pass adds a chunk's tiles in tile order instead of re-reading the tensor.  Same values as
