@@ -139,6 +139,9 @@ int ml_conv2d_ntile(int32_t cout, int32_t tile);
  * problems: launches too small to fill the chip with 128-wide tiles run on narrower ones (bit-identical results:
  * same k-ordered chains, split-K cut at the same k).  For reporting only; 0 on bad arguments. */
 int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace);
+/* M-tile height (128 / 256) of the same launch: ML_MATH_F32X3 launches that fill the chip with 256 x 128 tiles run the
+ * 8-wave software-pipelined form of the kernel (bit-identical results).  For reporting only; 0 on bad arguments. */
+int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace);
 /* Which persistent 1x1 kernel ml_conv2d_multi_f32 runs this single problem on: 1 = the tile-pipelined 128 x 128 kernel
  * (conv1x1_pipe.hip: the short-K bottleneck convs of engine/backbone/ResNext.py:199-231; fp32 or half tensors),
  * 2 = the 256 x 256-tile kernel for half tensors with K >= 256 (conv1x1_h256.hip: the ResNeXt-101 stage 2-4 convs of

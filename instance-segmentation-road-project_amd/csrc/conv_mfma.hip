@@ -151,6 +151,16 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
 // half wherever x is one, so |x - (hi + 2^-11 lo)| <= 2^-22 |x| for 2^-14 <= |x| < 65520 (smaller: 2^-36; beyond: hi overflows, the result is
 // Inf / NaN -- loud, as in the fp16-storage mode).  16 VALU instructions: 4 packed multiplies (x * 2^11), 4 packed converts,
 // 8 v_fma_mix (f16 hi * -2^11 + the scaled x, result stored as f16).
+__device__ __forceinline__ void split_hi_lo_pair(const float xa, const float xb, const float neg_scale, unsigned &hi, unsigned &lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {xa, xb};
+    const f32x2 sc = x * 2048.f;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[1]));
+}
+
 __device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, const float neg_scale, f16x8 &hi, f16x8 &lo) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -193,9 +203,13 @@ __device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, cons
 // fp64 -- the same folding as gn_stats_kernel) and writes one pair per WAVE (4 per tile) to `gn_partials`; the GroupNorm
 // apply pass adds the pairs of a chunk's tiles in order instead of re-reading the tensor (csrc/groupnorm.hip).  A separate
 // instantiation: the kernel every other conv runs is untouched.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false>
-__global__ void __launch_bounds__(256, (GNS || MATH == ML_MATH_F32X3) ? 2 : 1)      // (GNS: keep two blocks per CU -- 262 registers otherwise)
-conv_mfma_kernel(const MultiArgs args) {
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false, int NSTAGE = 2>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (GNS || MATH == ML_MATH_F32X3) ? 2 : 1)      // (second figure: waves per SIMD;
+conv_mfma_kernel(const MultiArgs args) {                                          //  GNS: 262 registers otherwise)
+    constexpr int NT = 64 * WAVES_M * WAVES_N;     // threads per block: 256 (4 waves), or 512 for the 256-row X3 tile
+    constexpr int RPP = NT / 8;                    // rows one staging pass of the block covers (8 lanes x 16 B per row)
+    static_assert(!GNS || NT == 256, "the GroupNorm partial sums are laid out for 4 waves per 128-row tile");
+    static_assert(NSTAGE == 2 || (NSTAGE == 3 && MATH == ML_MATH_F32X3), "the 3-deep ring is the X3 form");
     constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
     constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
     constexpr bool X3 = MATH == ML_MATH_F32X3;     // fp32 tensors, staged like ML_MATH_F32; split products on the f16 MFMA
@@ -203,8 +217,8 @@ conv_mfma_kernel(const MultiArgs args) {
     constexpr int KC = HS ? 64 : 32;               // elements per K chunk
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
-    constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
-    constexpr int B_LD = BN / 32;
+    constexpr int A_LD = BM / RPP;  // float4 loads per thread per chunk
+    constexpr int B_LD = BN / RPP;
     constexpr int BUF = F16 ? (BM + BN) * LDS_LD_H / 2 : (BM + BN) * LDS_LD;    // floats per staging buffer
     constexpr int C_LD = BN + 4;   // epilogue tile row stride (floats)
     // (the launcher sizes the dynamic LDS as max(two staging buffers, epilogue tile))
@@ -269,7 +283,7 @@ conv_mfma_kernel(const MultiArgs args) {
     // ~150 of the store loop) -- so what counts here is the instruction COUNT, not the latency.
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + ld_row + 32 * i;
+        const int m = m0 + ld_row + RPP * i;
         if (nohalo) {
             // output pixel m reads input pixel m: no (b, y, x) decomposition, no divisions
             a_iy0[i] = 0;
@@ -309,7 +323,7 @@ conv_mfma_kernel(const MultiArgs args) {
     // ---- residual tile prefetch: the epilogue's 4-channel x 16-row ownership is known up front, so
     // the (HBM-latency-bound) residual reads are issued now and fly under the whole K loop.
     constexpr int V_PER_ROW = BN / 4;               // float4 per tile row
-    constexpr int ROWS_PER_PASS = 256 / V_PER_ROW;  // rows covered by the block per pass
+    constexpr int ROWS_PER_PASS = NT / V_PER_ROW;   // rows covered by the block per pass
     constexpr int E_ROWS = BM / ROWS_PER_PASS;      // rows per thread in the epilogue
     const int c4 = (tid % V_PER_ROW) * 4;
     const int r0 = tid / V_PER_ROW;
@@ -359,7 +373,7 @@ conv_mfma_kernel(const MultiArgs args) {
     __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, wgt_bytes, 0x00020000);
     int b_voff[B_LD];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + 32 * i) * ktot + ld_c) * ES;
+    for (int i = 0; i < B_LD; ++i) b_voff[i] = ((n0 + ld_row + RPP * i) * ktot + ld_c) * ES;
     auto piece_a = [&](int i) {
         int vo = a_voff[i] + toff * ES;
         if (!nohalo) {                            // wave-uniform
@@ -372,14 +386,14 @@ conv_mfma_kernel(const MultiArgs args) {
             areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, 0, 0));
         } else {
             // global -> LDS without a register round trip: this wave's 64 x 16 B = rows 32i + 8w .. +7 of the tile
-            load_b128_to_lds(rsrc_a, lds + dst_buf * BUF + (32 * i + 8 * wave_u) * LDS_LD, vo, 0);
+            load_b128_to_lds(rsrc_a, lds + dst_buf * BUF + (RPP * i + 8 * wave_u) * LDS_LD, vo, 0);
         }
     };
     auto piece_b = [&](int i, int kc) {
         if constexpr (F16) {
             breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], kc * 128, 0));
         } else {
-            load_b128_to_lds(rsrc_b, lds + dst_buf * BUF + (BM + 32 * i + 8 * wave_u) * LDS_LD, b_voff[i], kc * 128);
+            load_b128_to_lds(rsrc_b, lds + dst_buf * BUF + (BM + RPP * i + 8 * wave_u) * LDS_LD, b_voff[i], kc * 128);
         }
     };
     auto piece_end = [&]() {                     // advance (kh, kw, cc) and the running offsets with selects
@@ -407,12 +421,12 @@ conv_mfma_kernel(const MultiArgs args) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const f16x4 hv = {(_Float16)areg[i][0], (_Float16)areg[i][1], (_Float16)areg[i][2], (_Float16)areg[i][3]};
-                *reinterpret_cast<f16x4 *>(As + (ld_row + 32 * i) * LDS_LD_H + ld_c) = hv;
+                *reinterpret_cast<f16x4 *>(As + (ld_row + RPP * i) * LDS_LD_H + ld_c) = hv;
             }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
                 const f16x4 hv = {(_Float16)breg[i][0], (_Float16)breg[i][1], (_Float16)breg[i][2], (_Float16)breg[i][3]};
-                *reinterpret_cast<f16x4 *>(Bs + (ld_row + 32 * i) * LDS_LD_H + ld_c) = hv;
+                *reinterpret_cast<f16x4 *>(Bs + (ld_row + RPP * i) * LDS_LD_H + ld_c) = hv;
             }
             return;
         }
@@ -445,21 +459,139 @@ conv_mfma_kernel(const MultiArgs args) {
     const int b_off = F16 ? BM * LDS_LD_H + (wn * TN * 32 + r) * LDS_LD_H + h * 8 : BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD;
     const int swz = (r >> 1) & 7;                         // f32 math: k-group kg of row r sits in slot kg ^ swz
 
+    // NSTAGE = 3 (the 256-row X3 tile): a ring of three staging buffers, the prefetch runs TWO chunks ahead and a chunk
+    // ends with a counted wait (the loads of the chunk issued one iteration earlier have landed; this iteration's are
+    // still in flight) -- an X3 chunk is 24 MFMAs of 32 cycles, shorter than the L2 -> LDS latency.
+    constexpr int NLOADS = A_LD + B_LD;              // LDS-direct loads per thread and chunk
+    constexpr int AHEAD = NSTAGE - 1;
     if (kc_begin < kc_end) {
         load_chunk(kc_begin);
-        store_chunk(0);
+        if constexpr (NSTAGE == 3) {
+            const bool two = kc_begin + 1 < kc_end;
+            rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, two ? in_bytes : 0, 0x00020000);
+            rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, two ? wgt_bytes : 0, 0x00020000);
+            dst_buf = 1;
+            load_chunk(two ? kc_begin + 1 : kc_begin);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+        } else {
+            store_chunk(0);
+        }
     }
-    __syncthreads();
+    if constexpr (NSTAGE == 3) __builtin_amdgcn_s_barrier();
+    else __syncthreads();
 
+    if constexpr (X3 && NSTAGE == 3) {
+        // ---- the 256-row X3 tile: a software pipeline over the 16-deep steps.  The MFMAs of one step run while the NEXT
+        // step's fragments are read from LDS and its A fragment is split (VALU) -- within a wave, instruction by instruction:
+        // two waves of a SIMD that reach a barrier together would otherwise split together and then queue for the matrix
+        // pipe together (measured: the un-pipelined form gains nothing from the larger tile).  The chunk's barrier sits
+        // BETWEEN its two steps: behind it the next chunk (requested a whole chunk earlier) is visible, so the second
+        // step's MFMAs cover the first fragments of that chunk; the buffer the new requests overwrite was last read
+        // before the previous barrier.
+        static_assert(TM == 1, "one A fragment per wave");
+        constexpr int NPA = (NLOADS + 1) / 2;                 // loads requested in the first half of a chunk
+        const float neg_scale = -2048.f;
+        f16x8 ahA, alA, ahB, alB, bhA[TN], bhB[TN], bl[TN];
+        f32x4 rx0, rx1;                                       // the next step's A fragment as staged (fp32)
+        unsigned hw[4], lw[4];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        auto ld_a_raw = [&](const float *b, int ks) {
+            const float *row = b + a_off;
+            rx0 = *reinterpret_cast<const f32x4 *>(row + (((ks * 4 + 2 * h) ^ swz) * 4));
+            rx1 = *reinterpret_cast<const f32x4 *>(row + (((ks * 4 + 2 * h + 1) ^ swz) * 4));
+        };
+        auto ld_bh = [&](const float *b, int ks, f16x8 (&bh)[TN]) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                bh[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(b + b_off + ni * 32 * LDS_LD + (((ks * 2 + h) ^ swz) * 4)));
+        };
+        auto ld_bl = [&](const float *b, int ks) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                bl[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(b + b_off + ni * 32 * LDS_LD + (((4 + ks * 2 + h) ^ swz) * 4)));
+        };
+        auto split_pair = [&](int q) {                        // elements 2q, 2q + 1 of the staged fragment: 4 VALU instructions
+            const float xa = q < 2 ? rx0[2 * (q & 1)] : rx1[2 * (q & 1)], xb = q < 2 ? rx0[2 * (q & 1) + 1] : rx1[2 * (q & 1) + 1];
+            split_hi_lo_pair(xa, xb, neg_scale, hw[q], lw[q]);
+        };
+        auto pack = [&](f16x8 &hi, f16x8 &lo) {
+            const u32x4 H = {hw[0], hw[1], hw[2], hw[3]}, L = {lw[0], lw[1], lw[2], lw[3]};
+            hi = __builtin_bit_cast(f16x8, H);
+            lo = __builtin_bit_cast(f16x8, L);
+        };
+        auto piece = [&](int q, int kcn) {
+            if (q < A_LD) piece_a(q);
+            else if (q < A_LD + B_LD) piece_b(q - A_LD, kcn);
+            else piece_end();
+        };
+        // one step: 12 MFMAs on (ahC, alC, bhC, bl); the next step (buffer nb, step nks) is fetched into (ahN, alN, bhN, bl)
+        auto step = [&](const f16x8 &ahC, const f16x8 &alC, f16x8 (&bhC)[TN], const float *nb, int nks, f16x8 &ahN, f16x8 &alN,
+                        f16x8 (&bhN)[TN], int q0, int q1, int kcn) {
+            int q = q0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {                 // cross term 1: hi_a x lo_b
+                accx[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahC, bl[ni], accx[0][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ni == 0) { ld_a_raw(nb, nks); ld_bh(nb, nks, bhN); }
+                else if (q < q1) piece(q++, kcn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ld_bl(nb, nks);                                   // (bl is dead: the next step's low halves of B)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {                 // cross term 2: lo_a x hi_b; the next A fragment is split beside it
+                accx[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alC, bhC[ni], accx[0][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                split_pair(ni);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {                 // hi_a x hi_b
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahC, bhC[ni], acc[0][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < q1) piece(q++, kcn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pack(ahN, alN);
+        };
+        static_assert(TN == 4, "split_pair(ni) covers the 4 pairs of a fragment");
+        if (kc_begin < kc_end) {                              // fragments of (first chunk, step 0): exposed once per tile
+            ld_a_raw(lds, 0);
+            ld_bh(lds, 0, bhA);
+            ld_bl(lds, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split_pair(q);
+            pack(ahA, alA);
+        }
+        int buf = 0;
+        for (int kc = kc_begin; kc < kc_end; ++kc) {
+            const bool more = kc + 2 < kc_end;
+            const int kc_next = more ? kc + 2 : kc;
+            rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, more ? in_bytes : 0, 0x00020000);
+            rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, more ? wgt_bytes : 0, 0x00020000);
+            const float *base = lds + buf * BUF;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+            dst_buf = buf == 0 ? 2 : buf - 1;
+            piece_begin();
+            __builtin_amdgcn_sched_barrier(0);
+            step(ahA, alA, bhA, base, 1, ahB, alB, bhB, 0, NPA, kc_next);
+            // the chunk after this one has landed (requested during the previous iteration; only this iteration's NPA
+            // requests may still be in flight) -- and every wave is past its last read of the buffer being refilled
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            step(ahB, alB, bhB, lds + nbuf * BUF, 0, ahA, alA, bhA, NPA, NLOADS + 1, kc_next);
+            buf = nbuf;
+        }
+    } else {
+    int buf = 0;
     for (int kc = kc_begin; kc < kc_end; ++kc) {
-        const int buf = (kc - kc_begin) & 1;
-        const bool more = kc + 1 < kc_end;
-        // Unconditional prefetch, no branch: on the last iteration it goes through empty resources (no traffic).
-        const int kc_next = more ? kc + 1 : kc;
+        const bool more = kc + AHEAD < kc_end;
+        // Unconditional prefetch, no branch: on the last iteration(s) it goes through empty resources (no traffic).
+        const int kc_next = more ? kc + AHEAD : kc;
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)pin, 0, more ? in_bytes : 0, 0x00020000);
         rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, more ? wgt_bytes : 0, 0x00020000);
         const float *base = lds + buf * BUF;
-        dst_buf = buf ^ 1;
+        dst_buf = NSTAGE == 3 ? (buf == 0 ? 2 : buf - 1) : (buf ^ 1);
         piece_begin();
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NPIECE = A_LD + B_LD + 1;              // + piece_end
@@ -609,9 +741,21 @@ conv_mfma_kernel(const MultiArgs args) {
         }
         if constexpr (F16) {
             if (more) store_chunk(buf ^ 1);
+        } else if constexpr (NSTAGE == 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");      // the NEXT chunk's rows have landed
         } else {
             store_chunk(buf ^ 1);        // always: the (dropped) last prefetch must have landed before the epilogue re-uses the LDS
         }
+        // (__syncthreads() is a fence too: the compiler puts s_waitcnt vmcnt(0) in front of it, which would wait for the
+        // chunk that was only just requested; the bare barrier is enough -- every wave's reads of `buf` were consumed by
+        // its MFMAs before it gets here, and the next writes into `buf` are issued after the barrier)
+        if constexpr (NSTAGE == 3) __builtin_amdgcn_s_barrier();
+        else __syncthreads();
+        buf = NSTAGE == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
+    }
+    }
+    if constexpr (NSTAGE == 3) {         // (the dropped last prefetches: nothing may still be writing when the epilogue re-uses the LDS)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -867,18 +1011,19 @@ int choose_splits(long long tiles, int chunks) {
 
 // split_tiles >= 0: the tile count the split-K decision is taken on (see narrow_tile_for_small_launch), else this
 // launch's own
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false, int NSTAGE = 2>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s,
                  long long split_tiles = -1) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr bool F16 = MATH == ML_MATH_F16;
     constexpr int ES = MATH == ML_MATH_F16S ? 2 : 4, KC = MATH == ML_MATH_F16S ? 64 : 32;
-    constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : 2 * (BM + BN) * LDS_LD * 4;
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : NSTAGE * (BM + BN) * LDS_LD * 4;
     constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
     constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     constexpr int LDS_BYTES = LDS_BYTES0;
-    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH, GNS>;
+    auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH, GNS, NSTAGE>;
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "conv2d")) return rc;
     MultiArgs args;
@@ -935,7 +1080,7 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         ML_REQUIRE(start < (1ll << 31), "conv2d: grid too large");
     }
     args.start[n] = (int)start;
-    hipLaunchKernelGGL(kern, dim3((unsigned)start), dim3(256), LDS_BYTES, s, args);
+    hipLaunchKernelGGL(kern, dim3((unsigned)start), dim3(NT), LDS_BYTES, s, args);
     ML_CHECK_LAUNCH("conv2d");
     ReduceArgs ra;
     ra.n = 0;
@@ -1067,6 +1212,19 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
     return t0;
 }
 
+// ML_MATH_F32X3: 256 x 128 tiles (8 waves, one block per CU, 3-deep ring, software-pipelined steps) once they fill the
+// chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB.  Not with gn_partials (their layout is
+// per 128-row tile and 4 waves).  Results are bit-identical to the 128-row kernel's: the same k-ordered chains.
+static bool x3_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
+    if (t != 1 || descs[0].math != ML_MATH_F32X3) return false;
+    long long big = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].gn_partials) return false;
+        big += (((long long)descs[i].B * descs[i].Ho * descs[i].Wo + 255) / 256) * (descs[i].n_pad / 128);
+    }
+    return big >= ml_resident_blocks(1);
+}
+
 extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in, void *workspace, int64_t workspace_bytes,
                                    void *stream) {
     ML_REQUIRE(descs_in != nullptr && n_in >= 1 && n_in <= MAXP, "conv2d: need 1..%d problems", MAXP);
@@ -1130,10 +1288,14 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     for (int i = 0; i < n; ++i) any_gns = any_gns || descs[i].gn_partials != nullptr;
     ML_REQUIRE(!any_gns || t == 1, "conv2d: gn_partials needs the fp32 128 x 128 kernel (a launch of >= 257 tiles)");
     if (descs[0].math == ML_MATH_F32X3) {
-        if (any_gns) return launch_multi<2, 2, 2, 2, ML_MATH_F32X3, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        // Wave layout 4 x 1 (a wave = 32 rows x the whole N tile): the A fragments -- the operand that is split in
+        // registers -- are read and split by ONE wave instead of two (+3-5 % on the 3x3 convs against 2 x 2 waves).
+        if (any_gns) return launch_multi<4, 1, 1, 4, ML_MATH_F32X3, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        if (x3_uses_256_row_tiles(descs, n, t))
+            return launch_multi<8, 1, 1, 4, ML_MATH_F32X3, false, 3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         switch (t) {
-            case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-            case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 1: return launch_multi<4, 1, 1, 4, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+            case 2: return launch_multi<4, 1, 1, 2, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
             default: return launch_multi<4, 1, 1, 1, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         }
     }
@@ -1153,6 +1315,15 @@ extern "C" int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, in
     long long ref_tiles = -1;
     const int t = narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles);
     return t == 1 ? 128 : (t == 2 ? 64 : 32);
+}
+
+// M-tile height (128 / 256) of the same launch; 0 on bad arguments.
+extern "C" int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, int32_t has_workspace) {
+    if (!descs || n < 1 || n > MAXP) return 0;
+    const int t0 = pick_tile(descs[0].cout, descs[0].tile);
+    long long ref_tiles = -1;
+    const int t = narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles);
+    return x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
 }
 
 extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {

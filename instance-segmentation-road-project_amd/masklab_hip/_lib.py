@@ -68,6 +68,7 @@ SIGNATURES = {
     "ml_conv2d_ntile": (C.c_int, [_i32, _i32]),
     "ml_conv2d_uses_pipe": (C.c_int, [C.POINTER(ConvDesc)]),
     "ml_conv2d_launch_ntile": (C.c_int, [C.POINTER(ConvDesc), _i32, _i32]),
+    "ml_conv2d_launch_mtile": (C.c_int, [C.POINTER(ConvDesc), _i32, _i32]),
     "ml_conv2d_workspace_bytes": (_i64, []),
     "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
     "ml_deconv2x2_out1x1_f32": (C.c_int, [C.POINTER(DeconvOutProblem), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

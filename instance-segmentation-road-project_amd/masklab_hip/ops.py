@@ -249,9 +249,10 @@ def _conv_kernel_name(p, descs=None, n=1, half=False):
     asked which N tile it will really use: small launches run on narrower tiles than the weights were packed for."""
     lib = _lib.load()
     bn = lib.ml_conv2d_launch_ntile(descs, n, 1) if descs is not None and PROFILE is not None else 0
+    bm = (lib.ml_conv2d_launch_mtile(descs, n, 1) if bn else 0) or 128
     if not bn:
         bn = lib.ml_conv2d_ntile(p.cout, p.tile)
-    return "conv_mfma_128x%d%s%s" % (bn, "_grouped" if p.group_cin_step else "",
+    return "conv_mfma_%dx%d%s%s" % (bm, bn, "_grouped" if p.group_cin_step else "",
                                      "_h" if half else {"f32": "", "f32x3": "_x3"}.get(CONV_MATH, "_f16"))
 
 

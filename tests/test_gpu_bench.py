@@ -54,6 +54,11 @@ def test_bench_json_contract_single_rank():
     assert d["parity"]["rows_exact"] is True and d["parity"]["order_exact"] is True
     assert all("hbm_frac" in v or "mfma_frac" in v for k, v in d["kernels"].items()
                if k.startswith(("conv_mfma", "groupnorm", "gconv3x3")))
+    # the extra leg under the split-operand conv math: beside `value`, same protocol, its own parity block
+    x3 = d["f32x3"]
+    assert x3["value"] > 0 and x3["steps"] == 2 and x3["warmup"] == 1 and x3["unit"] == "images/sec"
+    assert x3["parity"]["ok"] is True and x3["parity"]["order_exact"] is True and x3["parity"]["rows_exact"] is True
+    assert d["dtype"] == "f32" and "f16 MFMA" in x3["dtype"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

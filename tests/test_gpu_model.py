@@ -208,8 +208,11 @@ def test_hipgraph_replay_equals_eager(bt):
     want = model.predict(other)
     model.enable_graphs(True)
     got = model.predict(other)
-    for g, r in zip(got, want):
-        np.testing.assert_array_equal(g, r)
+    for name, g, r in zip(model.output_names, got, want):
+        if name == "roi_masks":                            # (eager = RoI batches sized by the host read, graph = at capacity: see above)
+            np.testing.assert_allclose(g, r, atol=1e-5, err_msg=name)
+        else:
+            np.testing.assert_array_equal(g, r, err_msg=name)
     model.enable_graphs(False)
 
 
