@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (GNS || MATH == ML_MAT
 conv_mfma_kernel(const MultiArgs args) {                                          //  GNS: 262 registers otherwise)
     constexpr int NT = 64 * WAVES_M * WAVES_N;     // threads per block: 256 (4 waves), or 512 for the 256-row X3 tile
     constexpr int RPP = NT / 8;                    // rows one staging pass of the block covers (8 lanes x 16 B per row)
-    static_assert(!GNS || NT == 256, "the GroupNorm partial sums are laid out for 4 waves per 128-row tile");
+    static_assert(!GNS || (NT == 256 && WAVES_M * TM == 4) || (NT == 512 && WAVES_M * TM == 8),
+                  "the GroupNorm partial sums: 4 pairs per 128-row tile, from 4 waves or from 8 waves on 256 rows");
     static_assert(NSTAGE == 2 || (NSTAGE == 3 && MATH == ML_MATH_F32X3), "the 3-deep ring is the X3 form");
     constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
     constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
@@ -830,7 +831,8 @@ conv_mfma_kernel(const MultiArgs args) {                                        
         } else if (full && !late_res && !p.out_bstride) {
             float *op = p.out + off;
             const size_t step = (size_t)ROWS_PER_PASS * cs;
-            double gs = 0.0, gq = 0.0;
+            constexpr int HALVES = BM / 128;                 // 128-row tiles the partial sums are kept for
+            double gs[HALVES] = {}, gq[HALVES] = {};
 #pragma unroll
             for (int i = 0; i < E_ROWS; ++i) {
                 f32x4 v = tile_v[i];
@@ -843,21 +845,45 @@ conv_mfma_kernel(const MultiArgs args) {                                        
                 if constexpr (GNS) {
                     const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
                     const float q4 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                    gs += (double)s4;
-                    gq += (double)q4;
+                    gs[i * HALVES / E_ROWS] += (double)s4;   // (rows r0 + i * ROWS_PER_PASS, r0 < ROWS_PER_PASS)
+                    gq[i * HALVES / E_ROWS] += (double)q4;
                 }
             }
             if constexpr (GNS) {
                 if (p.gn_partials) {                           // (block-uniform)
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        gs += __shfl_down(gs, o, 64);
-                        gq += __shfl_down(gq, o, 64);
-                    }
-                    // one pair per WAVE (a tile's rows 2w, 2w + 1 mod 8): no cross-wave step, no barrier
-                    if (lane == 0) {
-                        p.gn_partials[2 * ((size_t)mt * 4 + wave)] = gs;
-                        p.gn_partials[2 * ((size_t)mt * 4 + wave) + 1] = gq;
+                    for (int hh = 0; hh < HALVES; ++hh)
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            gs[hh] += __shfl_down(gs[hh], o, 64);
+                            gq[hh] += __shfl_down(gq[hh], o, 64);
+                        }
+                    if constexpr (NT == 256) {
+                        // one pair per WAVE (a tile's rows 2w, 2w + 1 mod 8): no cross-wave step, no barrier
+                        if (lane == 0) {
+                            p.gn_partials[2 * ((size_t)mt * 4 + wave)] = gs[0];
+                            p.gn_partials[2 * ((size_t)mt * 4 + wave) + 1] = gq[0];
+                        }
+                    } else {
+                        // 8 waves on a 256-row tile: waves w and w + 4 hold the rows 2w, 2w + 1 mod 8 of BOTH 128-row
+                        // halves; the pair of a (half, slot) is the sum of the two, through LDS behind the transposed tile
+                        double *scr = reinterpret_cast<double *>(lds + BM * C_LD);
+                        if (lane == 0) {
+#pragma unroll
+                            for (int hh = 0; hh < HALVES; ++hh) {
+                                scr[(wave * HALVES + hh) * 2] = gs[hh];
+                                scr[(wave * HALVES + hh) * 2 + 1] = gq[hh];
+                            }
+                        }
+                        __syncthreads();
+                        if (wave < 4 && lane == 0) {
+#pragma unroll
+                            for (int hh = 0; hh < HALVES; ++hh) {
+                                const size_t slot = 2 * (((size_t)mt * HALVES + hh) * 4 + wave);
+                                p.gn_partials[slot] = scr[(wave * HALVES + hh) * 2] + scr[((wave + 4) * HALVES + hh) * 2];
+                                p.gn_partials[slot + 1] = scr[(wave * HALVES + hh) * 2 + 1] + scr[((wave + 4) * HALVES + hh) * 2 + 1];
+                            }
+                        }
                     }
                 }
             }
@@ -1020,7 +1046,8 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     constexpr int ES = MATH == ML_MATH_F16S ? 2 : 4, KC = MATH == ML_MATH_F16S ? 64 : 32;
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int STAGE_BYTES = F16 ? 2 * (BM + BN) * LDS_LD_H * 2 : NSTAGE * (BM + BN) * LDS_LD * 4;
-    constexpr int EPI_BYTES = BM * (BN + 4) * 4;           // the epilogue's transposed tile re-uses the staging LDS
+    constexpr int EPI_BYTES = BM * (BN + 4) * 4 + (GNS && NT == 512 ? 256 : 0);   // the epilogue's transposed tile re-uses the staging LDS
+                                                                                  // (+ 8 waves x 2 halves x 2 doubles of GroupNorm partial sums)
     constexpr int LDS_BYTES0 = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     constexpr int LDS_BYTES = LDS_BYTES0;
     auto kern = conv_mfma_kernel<WAVES_M, WAVES_N, TM, TN, MATH, GNS, NSTAGE>;
@@ -1213,14 +1240,14 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
 }
 
 // ML_MATH_F32X3: 256 x 128 tiles (8 waves, one block per CU, 3-deep ring, software-pipelined steps) once they fill the
-// chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB.  Not with gn_partials (their layout is
-// per 128-row tile and 4 waves).  Results are bit-identical to the 128-row kernel's: the same k-ordered chains.
+// chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB.  Results are bit-identical to the 128-row kernel's: the same k-ordered chains.
 static bool x3_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
     if (t != 1 || descs[0].math != ML_MATH_F32X3) return false;
     long long big = 0;
     for (int i = 0; i < n; ++i) {
-        if (descs[i].gn_partials) return false;
-        big += (((long long)descs[i].B * descs[i].Ho * descs[i].Wo + 255) / 256) * (descs[i].n_pad / 128);
+        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
+        if (descs[i].gn_partials && M % 256) return false;      // (the partial sums are written by whole tiles only)
+        big += ((M + 255) / 256) * (descs[i].n_pad / 128);
     }
     return big >= ml_resident_blocks(1);
 }
@@ -1290,9 +1317,11 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     if (descs[0].math == ML_MATH_F32X3) {
         // Wave layout 4 x 1 (a wave = 32 rows x the whole N tile): the A fragments -- the operand that is split in
         // registers -- are read and split by ONE wave instead of two (+3-5 % on the 3x3 convs against 2 x 2 waves).
-        if (any_gns) return launch_multi<4, 1, 1, 4, ML_MATH_F32X3, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
-        if (x3_uses_256_row_tiles(descs, n, t))
+        if (x3_uses_256_row_tiles(descs, n, t)) {
+            if (any_gns) return launch_multi<8, 1, 1, 4, ML_MATH_F32X3, true, 3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
             return launch_multi<8, 1, 1, 4, ML_MATH_F32X3, false, 3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
+        }
+        if (any_gns) return launch_multi<4, 1, 1, 4, ML_MATH_F32X3, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         switch (t) {
             case 1: return launch_multi<4, 1, 1, 4, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
             case 2: return launch_multi<4, 1, 1, 2, ML_MATH_F32X3>(descs, n, workspace, workspace_bytes, s, ref_tiles);

@@ -212,6 +212,37 @@ def test_256_row_pipelined_tile(k, cin, cout, shape, res, dil, n_small):
     np.testing.assert_allclose(big[B - 1:], T.relu(ref), rtol=0, atol=2e-5)
 
 
+def test_groupnorm_partials_from_the_256_row_tile():
+    """ml_conv2d_desc.gn_partials from the 8-wave kernel: 4 pairs per 128-row tile like the 4-wave kernel writes (waves w and
+    w + 4 added through LDS), so the GroupNorm apply pass is unchanged."""
+    from masklab_hip import _lib, ops, packing
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    B, H, W = 4, 128, 128                                        # 256 tiles of 256 rows
+    x = rng.normal(size=(B, H, W, 128)).astype(np.float32)
+    w, b = (rng.normal(size=(3, 3, 128, 128)) * 0.03).astype(np.float32), rng.normal(size=(128,)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, 128).astype(np.float32), rng.normal(size=(128,)).astype(np.float32)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    plain = ops.conv2d(dev(x), dc, act=_lib.ACT_RELU)
+    want = host(ops.groupnorm_chunk(plain, dev(gamma), dev(beta), 16))
+    part = torch.full((B * H * W // 128, 4, 2), float("nan"), dtype=torch.float64, device="cuda")
+    xd = dev(x)
+    d, _, _ = ops._conv_desc(xd, dc, act=_lib.ACT_RELU, gn_partials=part)
+    assert _lib.load().ml_conv2d_launch_mtile(C.byref(d), 1, 1) == 256
+    y = ops.conv2d(xd, dc, act=_lib.ACT_RELU, gn_partials=part)
+    np.testing.assert_array_equal(host(y), host(plain))
+    yh = host(y).astype(np.float64).reshape(-1, 128 * 128)
+    np.testing.assert_allclose(host(part)[..., 0].sum(1), yh.sum(1), rtol=1e-7)
+    np.testing.assert_allclose(host(part)[..., 1].sum(1), (yh * yh).sum(1), rtol=1e-6)
+    (got,) = ops.groupnorm_chunk_multi([dict(x=y, gamma=dev(gamma), beta=dev(beta), groups=16, out=y, partials=(part, 32))])
+    np.testing.assert_allclose(host(got), want, rtol=0, atol=2e-6)
+    # three images of the same batch: 192 tiles of 256 rows -> the 4-wave kernel; the normalised outputs agree bit for bit
+    part3 = torch.full((3 * H * W // 128, 4, 2), float("nan"), dtype=torch.float64, device="cuda")
+    y3 = ops.conv2d(dev(x[:3]), dc, act=_lib.ACT_RELU, gn_partials=part3)
+    (got3,) = ops.groupnorm_chunk_multi([dict(x=y3, gamma=dev(gamma), beta=dev(beta), groups=16, out=y3, partials=(part3, 32))])
+    np.testing.assert_array_equal(host(got3), host(got)[:3])
+
+
 def test_weights_are_split_once_on_the_host():
     """DeviceConv.wgt_x3: same bytes and strides as the fp32 packing; hi + 2^-11 lo reproduces every weight to 2^-22."""
     from masklab_hip import ops, packing
