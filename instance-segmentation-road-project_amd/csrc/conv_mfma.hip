@@ -315,9 +315,14 @@ conv_mfma_kernel(const MultiArgs args) {                                        
     const int total_chunks = p.KH * p.KW * ncpt;
     const int kc_begin = slice * P.cps;
     const int kc_end = min(kc_begin + P.cps, total_chunks);
-    // state of the NEXT chunk to load: kc -> (kh, kw, cc)
-    int cc = kc_begin % ncpt;
-    const int tap0 = kc_begin / ncpt;
+    // state of the NEXT chunk to load: kc -> (cc, kh, kw), TAPS INNERMOST.  All taps of one 32-channel slice run back to back:
+    // the blocks of an XCD (a contiguous range of panels, in step with one another) then work on rows x one channel slice
+    // -- ~1 MB at a 128-wide map -- for KH x KW chunks in a row, which the 4 MB L2 holds; with the channel slices innermost
+    // every tap walked the whole channel depth (4 MB and more) before the next tap came back to the same lines, and a
+    // 3x3 conv fetched its input 2-8 times from beyond L2 (round 3 shape PMC).  The weights stay packed tap-major.
+    const int ntaps = p.KH * p.KW;
+    int cc = kc_begin / ntaps;
+    const int tap0 = kc_begin - cc * ntaps;
     int kw = tap0 % p.KW;
     int kh = tap0 / p.KW;
 
@@ -349,8 +354,10 @@ conv_mfma_kernel(const MultiArgs args) {                                        
     // (tap, channel chunk) relative to a row's tap-(0,0) pixel -- updated with scalar adds only
     int dy = kh * pdil, dx = kw * pdil;
     int toff = (int)(((long long)dy * pW + dx) * pcs) + cc * KC;
-    const int step_kw = (int)(pdil * pcs) - (ncpt - 1) * KC;                       // next tap in the row
-    const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs) - (ncpt - 1) * KC;
+    const int pKH = p.KH;
+    const int step_kw = (int)(pdil * pcs);
+    const int step_kh = (int)((long long)pdil * pW * pcs) - (pKW - 1) * (int)(pdil * pcs);
+    const int step_cc = KC - (int)(((long long)(pKH - 1) * pdil * pW + (long long)(pKW - 1) * pdil) * pcs);
     // The next chunk's prefetch is split into PIECES (one A row or one B row each: ~12 VALU + 1 global
     // load) that the K loop pins between individual MFMAs with sched_barrier(0): a wave that issues MFMAs
     // back to back owns its SIMD's issue port, so non-MFMA work only overlaps matrix work when it sits in
@@ -392,20 +399,21 @@ conv_mfma_kernel(const MultiArgs args) {                                        
     };
     auto piece_b = [&](int i, int kc) {
         if constexpr (F16) {
-            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], kc * 128, 0));
+            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], ((kh * pKW + kw) * ncpt + cc) * 128, 0));
         } else {
-            load_b128_to_lds(rsrc_b, lds + dst_buf * BUF + (BM + RPP * i + 8 * wave_u) * LDS_LD, b_voff[i], kc * 128);
+            load_b128_to_lds(rsrc_b, lds + dst_buf * BUF + (BM + RPP * i + 8 * wave_u) * LDS_LD, b_voff[i], ((kh * pKW + kw) * ncpt + cc) * 128);
         }
     };
     auto piece_end = [&]() {                     // advance (kh, kw, cc) and the running offsets with selects
-        const bool wrap_c = (cc + 1 == ncpt);
-        const bool wrap_w = wrap_c && (kw + 1 == pKW);
-        toff += wrap_w ? step_kh : (wrap_c ? step_kw : KC);
-        dx = wrap_w ? 0 : (wrap_c ? dx + pdil : dx);
-        dy = wrap_w ? dy + pdil : dy;
-        kw = wrap_w ? 0 : (wrap_c ? kw + 1 : kw);
-        kh = wrap_w ? kh + 1 : kh;
-        cc = wrap_c ? 0 : cc + 1;
+        // (0 / 1 arithmetic, no select chains: with `?:` on three levels the compiler kept this state in scratch memory)
+        const int w = (kw + 1 == pKW) ? 1 : 0;
+        const int hh = w & ((kh + 1 == pKH) ? 1 : 0);
+        toff += step_kw + w * (step_kh - step_kw) + hh * (step_cc - step_kh);
+        dx = (1 - w) * (dx + pdil);
+        dy = (1 - hh) * (dy + w * pdil);
+        kw = (1 - w) * (kw + 1);
+        kh = (1 - hh) * (kh + w);
+        cc += hh;
     };
     auto load_chunk = [&](int kc) {              // un-interleaved form (prologue)
         piece_begin();
