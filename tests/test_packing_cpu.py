@@ -107,3 +107,37 @@ def test_ntile_matches_library():
     for cout in (1, 3, 5, 32, 33, 60, 64, 65, 75, 96, 97, 128, 256, 2048):
         for tile in (0, 1, 2, 3):
             assert lib.ml_conv2d_ntile(cout, tile) == packing.ntile_for(cout, tile)
+
+
+@pytest.mark.parametrize("pack", ["dense", "rowspan", "grouped"])
+def test_split_operand_weights_f32x3(pack):
+    """DeviceConv.wgt_x3 (ML_MATH_F32X3, include/masklab_hip.h): every 32-float chunk of a packed row becomes 32 halves
+    hi(w) then 32 halves 2^11 (w - hi(w)) -- same bytes, same strides, any packing; hi + 2^-11 lo gives every weight back
+    to 2^-22 (2^-36 absolute below the smallest normal half), zeros stay zeros, and the emulated conv on the
+    reconstructed weights matches the oracle like the fp32 packing does."""
+    torch = pytest.importorskip("torch")
+    from masklab_hip import ops
+    rng = np.random.default_rng(4)
+    if pack == "dense":
+        w = (rng.normal(size=(3, 3, 40, 72)) * 0.05).astype(np.float32)
+        p = packing.pack_dense(w, rng.normal(size=(72,)).astype(np.float32))
+    elif pack == "rowspan":
+        w = (rng.normal(size=(7, 7, 3, 64)) * 0.2).astype(np.float32)
+        p = packing.pack_rowspan(w, None)
+    else:
+        w = (rng.normal(size=(3, 3, 128, 4)) * 0.1).astype(np.float32)
+        p = packing.pack_grouped(w, 32)
+    dc = ops.DeviceConv(p, "cpu")
+    a, s = dc.wgt.numpy(), dc.wgt_x3.numpy()
+    assert a.shape == s.shape and s.dtype == np.float32 and s.flags["C_CONTIGUOUS"]
+    h = s.view(np.float16).reshape(a.shape[0], -1, 64).astype(np.float64)
+    assert np.isfinite(h).all()
+    back = (h[..., :32] + h[..., 32:] * 2.0 ** -11).reshape(a.shape)
+    assert np.all(np.abs(back - a) <= np.maximum(np.abs(a) * 2.0 ** -22, 2.0 ** -36))
+    assert np.all(back[a == 0] == 0)
+    if pack == "dense":
+        import dataclasses
+        x = rng.normal(size=(1, 9, 11, 40)).astype(np.float32)
+        ref = T.conv2d(x.astype(np.float64), w, p.bias)
+        got = emulate_conv(dataclasses.replace(p, wgt=back.astype(np.float32)), x)
+        np.testing.assert_allclose(got, ref, atol=2e-6)
