@@ -92,6 +92,8 @@ def parse_args():
                     help="one oracle forward only (parity + a single timing), no repeats / 1-thread / 512^2 legs")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32x3", action="store_true", help="skip the extra timed leg under the split-operand conv math")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timings of the other BASELINE configs' shapes (default workload, one GPU)")
     ap.add_argument("--dump-launches", default=None, help="write one line per profiled launch to this file")
     ap.add_argument("--host-inputs", action="store_true",
                     help="every step starts from pinned HOST uint8 images (PCIe-inclusive rate; not the headline)")
@@ -172,6 +174,39 @@ def build_model(backbone, device, seed=0, cls_scale=8.0):
             hot[k] = (w[k] * cls_scale).astype(np.float32)
     model.load_weights(hot, device)
     return cfg, model, w, hot
+
+
+def _time_config(workload, device, math, graph, rank, steps=20, warmup=3):
+    """One more model of WORKLOADS[workload], built, warmed and timed like the main loop (`steps` forwards between two
+    synchronisations, inputs resident in HBM), under conv math `math`; released afterwards."""
+    import numpy as np
+    import torch
+    from masklab_hip import ops
+    backbone, B, H, W = WORKLOADS[workload]
+    ops.set_conv_math(math)
+    model = None
+    try:
+        cfg, model, _w, _hot = build_model(backbone, device)
+        images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
+        if graph:
+            model.enable_graphs(True)
+        model(images, defer=graph)
+        torch.cuda.synchronize(device)
+        for _ in range(warmup):
+            model(images, defer=graph)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(images, defer=graph)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        return {"value": round(B * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
+                "steps": steps, "warmup": warmup, "per_gpu_batch": B, "height": H, "width": W, "hipgraph": bool(graph),
+                "dtype": ops.dtype_label()}
+    finally:
+        ops.set_conv_math("f32")
+        del model
+        torch.cuda.empty_cache()
 
 
 def _cpu_model():
@@ -571,6 +606,21 @@ def main():
         if alt is not None:
             alt["parity"] = extra.get("f32x3")
 
+    # ---- the other BASELINE configurations' per-GPU shapes, timed briefly in the same run so that the driver's record
+    # holds a number for them too (the default workload on one GPU only; never part of `value`; a failure here is recorded,
+    # not raised): configs[4]'s shard (ResNeXt-101, 16 x 1280^2, fp16 MFMA path with fp16 storage) and configs[0]
+    # (MobileNet, 1 x 512^2; whole-forward hipGraph), the latter under both fp32-tensor conv maths.
+    others = None
+    if rank == 0 and world == 1 and args.workload == "resnext50_full_b8_1024" and not args.no_other_configs:
+        others = {}
+        for key, wl, math, graph in (("resnext101_full_b16_1280_f16", "resnext101_full_b16_1280_f16", "f16s", False),
+                                     ("mobilenet_full_b1_512_graph", "mobilenet_full_b1_512", "f32", True),
+                                     ("mobilenet_full_b1_512_graph_f32x3", "mobilenet_full_b1_512", "f32x3", True)):
+            try:
+                others[key] = _time_config(wl, device, math, graph, rank)
+            except Exception as e:                       # noqa: BLE001 -- reported in the line
+                others[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         total_images = B * world * args.steps
         line = {
@@ -589,7 +639,8 @@ def main():
                                       f"({'gloo rehearsal' if rehearsal else 'RCCL'}), merged batch {gathered_images}")
                        if world > 1 else None,
                        "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "f32x3": alt, "kernels": per_kernel,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "f32x3": alt, "other_configs": others,
+            "kernels": per_kernel,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

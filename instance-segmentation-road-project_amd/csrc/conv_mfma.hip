@@ -1255,6 +1255,9 @@ static bool x3_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
     for (int i = 0; i < n; ++i) {
         const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
         if (descs[i].gn_partials && M % 256) return false;      // (the partial sums are written by whole tiles only)
+        // a residual is read in the epilogue (no registers to prefetch it) and one block per CU has nobody to cover that:
+        // with a K loop of a few chunks only (the 128 -> 256 conv3 of stage 1) two 128-row blocks per CU are faster
+        if (descs[i].residual && descs[i].KH * descs[i].KW * (descs[i].span_pad / 32) <= 4) return false;
         big += ((M + 255) / 256) * (descs[i].n_pad / 128);
     }
     return big >= ml_resident_blocks(1);

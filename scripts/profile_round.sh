@@ -11,7 +11,7 @@ WL=${2:-resnext50_full_b8_1024}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-f32x3"
+BENCH="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-f32x3 --no-other-configs"
 # (1a) kernels ALONE on the GPU (auxiliary streams off), like bench.py's instrumented roofline step: these average
 #      durations are the ones `roofline.avg_launch_us` must agree with
 export MASKLAB_SIDE_STREAM=0
@@ -27,7 +27,7 @@ echo "trace done"
 export MASKLAB_SIDE_STREAM=0
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE; do
   name=${pass%%:*}; ctr=${pass#*:}
-  rocprofv3 --kernel-trace --pmc ${ctr//,/ } --output-format rocpd -d $OUT/pmc_$name -o $name -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-f32x3 > $OUT/bench_pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc ${ctr//,/ } --output-format rocpd -d $OUT/pmc_$name -o $name -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-f32x3 --no-other-configs > $OUT/bench_pmc_$name.log 2>&1
   python3 scripts/rocpd_pmc_summary.py $(find $OUT/pmc_$name -name "*.db" | head -1) $OUT/pmc_$name.md > /dev/null
   echo "pmc $name done"
 done
