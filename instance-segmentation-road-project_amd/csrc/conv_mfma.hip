@@ -1247,6 +1247,17 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
     return t0;
 }
 
+// ML_MATH_F32X3, one 1x1 problem with a residual and a K loop of at most 8 chunks (the conv3 of ResNeXt stages 1 and 2):
+// HBM-bound, and half of a tile's time is its epilogue (residual in, result out) -- 128 x 64 tiles put three blocks on a
+// CU whose epilogues and K loops overlap (scripts/experiments/x3_tile_probe.py: 382 -> 355 us and 256 -> 238 us; longer
+// K loops lose).  Bit-identical results (same k-ordered chains).
+static int x3_adjust_tile(const ml_conv2d_desc *descs, int n, int t) {
+    if (descs[0].math != ML_MATH_F32X3 || t != 1 || n != 1) return t;
+    const ml_conv2d_desc &d = descs[0];
+    const bool short_k_res = d.residual && d.KH == 1 && d.KW == 1 && d.span_pad / 32 <= 8 && !d.gn_partials && !d.live;
+    return short_k_res ? 2 : t;
+}
+
 // ML_MATH_F32X3: 256 x 128 tiles (8 waves, one block per CU, 3-deep ring, software-pipelined steps) once they fill the
 // chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB.  Results are bit-identical to the 128-row kernel's: the same k-ordered chains.
 static bool x3_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
@@ -1307,7 +1318,7 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     if (workspace) ML_REQUIRE((((uintptr_t)workspace) & 255) == 0, "conv2d: workspace must be 256-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     long long ref_tiles = -1;
-    const int t = narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles);
+    const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles));
     if (descs[0].math == ML_MATH_F16S) {
         switch (t) {
             case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
@@ -1353,7 +1364,7 @@ extern "C" int ml_conv2d_launch_ntile(const ml_conv2d_desc *descs, int32_t n, in
     if (!descs || n < 1 || n > MAXP) return 0;
     const int t0 = pick_tile(descs[0].cout, descs[0].tile);
     long long ref_tiles = -1;
-    const int t = narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles);
+    const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles));
     return t == 1 ? 128 : (t == 2 ? 64 : 32);
 }
 
@@ -1362,7 +1373,7 @@ extern "C" int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, in
     if (!descs || n < 1 || n > MAXP) return 0;
     const int t0 = pick_tile(descs[0].cout, descs[0].tile);
     long long ref_tiles = -1;
-    const int t = narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles);
+    const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles));
     return x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
 }
 

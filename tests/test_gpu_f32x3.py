@@ -176,7 +176,7 @@ def test_operand_range_and_special_values():
 @pytest.mark.parametrize("k,cin,cout,shape,res,dil,n_small", [
     (3, 64, 128, (4, 128, 128), False, 1, 3),  # 256 tiles of 256 rows: the smallest launch that takes them; 18 chunks
     (1, 32, 128, (4, 128, 128), False, 1, 3),  # ONE chunk: the ring's second request goes through an empty resource
-    (1, 64, 256, (4, 128, 128), True, 1, 1),   # two chunks, two N tiles, residual
+    (1, 320, 256, (4, 128, 128), True, 1, 1),  # ten chunks, two N tiles, residual (read in the epilogue)
     (1, 96, 128, (5, 120, 111), False, 1, 3),  # three chunks, ragged last tile (66 600 rows)
     (3, 32, 128, (3, 160, 150), False, 2, 2),  # dilated taps, out-of-image rows through the out-of-range rule
 ])
@@ -210,6 +210,28 @@ def test_256_row_pipelined_tile(k, cin, cout, shape, res, dil, n_small):
     if res:
         ref = ref + r[B - 1:]
     np.testing.assert_allclose(big[B - 1:], T.relu(ref), rtol=0, atol=2e-5)
+
+
+def test_short_k_residual_1x1_runs_on_128x64_tiles():
+    """The conv3 shapes of ResNeXt stages 1 / 2 (K <= 256, residual): HBM-bound, half a tile's time is its epilogue -- three
+    128 x 64 blocks per CU overlap epilogues and K loops.  Same values as any other tile shape; checked against the oracle."""
+    from masklab_hip import _lib, ops, packing
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    x = rng.normal(size=(2, 96, 96, 128)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, 128, 256)) / np.sqrt(128)).astype(np.float32)
+    b = rng.normal(size=(256,)).astype(np.float32)
+    r = rng.normal(size=(2, 96, 96, 256)).astype(np.float32)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    xd, rd = dev(x), dev(r)
+    d, _, _ = ops._conv_desc(xd, dc, 1, "valid", 1, _lib.ACT_RELU, rd)
+    lib = _lib.load()
+    assert lib.ml_conv2d_launch_ntile(C.byref(d), 1, 1) == 64 and lib.ml_conv2d_launch_mtile(C.byref(d), 1, 1) == 128
+    got = host(ops.conv2d(xd, dc, padding="valid", act=_lib.ACT_RELU, residual=rd))
+    ref = T.relu(T.conv2d(x.astype(np.float64), w, b, 1, "valid") + r)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    d2, _, _ = ops._conv_desc(xd, dc, 1, "valid", 1, _lib.ACT_RELU, None)            # no residual: the rule does not apply
+    assert lib.ml_conv2d_launch_ntile(C.byref(d2), 1, 1) == 128
 
 
 def test_groupnorm_partials_from_the_256_row_tile():
