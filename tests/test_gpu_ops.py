@@ -139,6 +139,38 @@ def test_conv1x1_pipelined_kernel_is_the_default_for_short_k():
         ops.conv2d(dev(rnd(1, 8, 8, 64)), ops.DeviceConv(packing.pack_dense(rnd(3, 3, 64, 128), None, tile=4), "cuda"))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_conv2d_random_shapes(seed, conv_math):
+    """Seeded random geometry against the oracle: kernel 1 / 3 / 5 (also non-square maps), stride 1 / 2, dilation 1-3,
+    'same' / 'valid', channel counts off the tile grid, optional residual, every activation -- both conv maths."""
+    from masklab_hip import _lib, ops, packing
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([1, 3, 3, 5]))
+    stride = int(rng.choice([1, 1, 2]))
+    dil = 1 if (k == 1 or stride == 2) else int(rng.choice([1, 2, 3]))
+    cin = int(rng.choice([8, 24, 32, 40, 64, 96, 136, 256]))
+    cout = int(rng.choice([5, 32, 60, 75, 128, 130, 192, 256]))
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(5, 40)), int(rng.integers(5, 40))
+    padding = str(rng.choice(["same", "valid"]))
+    if padding == "valid" and min(H, W) <= dil * (k - 1):
+        padding = "same"
+    act = [None, "relu", "relu6", "sigmoid"][int(rng.integers(0, 4))]
+    x = (rng.normal(size=(B, H, W, cin))).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32) if rng.integers(0, 2) else None
+    ref = T.conv2d(x.astype(np.float64), w, b, stride, padding, dil)
+    res = None
+    if act != "sigmoid" and cout % 4 == 0 and rng.integers(0, 2):
+        res = rng.normal(size=ref.shape).astype(np.float32)
+        ref = ref + res
+    ref = {"relu": T.relu, "relu6": T.relu6, "sigmoid": T.sigmoid, None: lambda v: v}[act](ref)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    got = host(ops.conv2d(dev(x), dc, stride=stride, padding=padding, dilation=dil, act=_lib.ACT_BY_NAME[act],
+                          residual=None if res is None else dev(res)))
+    assert got.shape == ref.shape, (k, stride, dil, cin, cout, (B, H, W), padding, act)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5, err_msg=str((k, stride, dil, cin, cout, (B, H, W), padding, act)))
+
+
 def test_conv2d_residual_and_concat_slice(conv_math):
     from masklab_hip import _lib, ops, packing
     x, res = rnd(2, 12, 12, 64), rnd(2, 12, 12, 96)
