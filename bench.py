@@ -21,11 +21,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   in one step / their summed duration, timed with HIP events on the launch stream in an instrumented
                   step; peak = 157.3 TFLOP/s (fp32 MFMA).  `traffic` comes from a committed PMC pass only when that
                   pass was taken on the kernel sources this library was built from (hash check), else null.
-  cpu_baseline -- the NumPy oracle forward ("port", not TF-Keras) on the host cores: CPU model, BLAS threads, all-core,
-                  8-thread and 1-thread figures at 1x1024^2, all-core and 1-thread at 1x512^2 (warm-up + median),
-                  SURVEY 8(d); `value` = the fastest full-size setting, `cores` = its thread count.
-  parity       -- rank 0's first image through the GPU model vs the oracle at full size on an UN-saturated score
-                  fixture (oracle/fixtures.py): float outputs within 1e-3, (anchor, class) rows and their ORDER exact.
+  cpu_baseline -- the oracle forward (a CPU restatement of the reference, "port": not TF-Keras) on the host cores, two ways:
+                  pure NumPy / BLAS, and with its convolutions run by torch-CPU / oneDNN on all threads (what a competent
+                  CPU forward costs); CPU model, thread counts, 1x1024^2 and 1x512^2 samples (warm-up + median), SURVEY
+                  8(d); `value` = the fastest full-size setting, `cores` = its thread count.
+  parity       -- image 0 of ONE full-batch GPU forward (the launch shapes that are timed) vs the oracle at full size on an
+                  UN-saturated score fixture (oracle/fixtures.py): float outputs within 1e-3, (anchor, class) rows and
+                  their ORDER exact.  The oracle is parity-UNPINNED against TensorFlow.
 """
 import argparse
 import hashlib
@@ -135,30 +137,45 @@ def csrc_hash():
     return h.hexdigest()
 
 
-def measured_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/*_traffic.json,
-    scripts/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH x2
-    gfx950 correction) -- ONLY if that pass recorded the hash of the current kernel sources; a stale pass gives None."""
+# bench.py kernel label -> substring of the demangled kernel name in a rocprofv3 pass (a label covers every instantiation
+# of that tile shape: the plain kernel and the one that also writes the GroupNorm partial sums -- their launches are
+# averaged together, weighted by dispatches)
+_TRAFFIC_KERNELS = {
+    "conv_mfma_128x128": ("conv_mfma_kernel<2, 2, 2, 2, 0,",), "conv_mfma_128x64": ("conv_mfma_kernel<2, 2, 2, 1, 0,",),
+    "conv_mfma_128x32": ("conv_mfma_kernel<4, 1, 1, 1, 0,",),
+    "conv_mfma_256x128_x3": ("conv_mfma_kernel<8, 1, 1, 4, 3,",), "conv_mfma_128x128_x3": ("conv_mfma_kernel<4, 1, 1, 4, 3,",),
+    "conv_mfma_128x64_x3": ("conv_mfma_kernel<4, 1, 1, 2, 3,",),
+    "conv_mfma_128x128_h": ("conv_mfma_kernel<2, 2, 2, 2, 2,",),
+    "conv1x1_h256_h": ("conv1x1_h256_kernel", "conv1x1_h8_kernel"), "conv1x1_pipe_h": ("conv1x1_pipe_kernel<_Float16",),
+    "conv1x1_pipe": ("conv1x1_pipe_kernel<float",), "gconv3x3_mfma4_h": ("gconv_mfma4h_kernel", "gconv16h_kernel"),
+}
+
+
+def measured_traffic(kernel_label, workload="resnext50_full_b8_1024"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass of THIS workload
+    (profiles/*traffic.json, scripts/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH x2 gfx950 correction) -- ONLY if that pass recorded the hash of the current kernel sources; a stale
+    pass gives None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    # (a label covers every instantiation of that tile shape: the plain kernel and the one that also writes the
-    # GroupNorm partial sums -- their launches are averaged together, weighted by dispatches)
-    want = {"conv_mfma_128x128": "conv_mfma_kernel<2, 2, 2, 2, 0,", "conv_mfma_128x64": "conv_mfma_kernel<2, 2, 2, 1, 0,",
-            "conv_mfma_128x32": "conv_mfma_kernel<4, 1, 1, 1, 0,"}.get(kernel_label)
-    if not files or want is None:
+    want = _TRAFFIC_KERNELS.get(kernel_label)
+    if want is None:
         return None
     try:
-        doc = json.load(open(files[-1]))
-        if doc.get("source_sha256") != csrc_hash():
-            return None
-        tot = n = 0
-        for k, v in doc["kernels"].items():
-            if want in k:
-                tot += v["hbm_bytes_per_launch"] * v["dispatches"]
-                n += v["dispatches"]
-        return round(tot / n) if n else None
+        h = csrc_hash()
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")), reverse=True):
+            doc = json.load(open(f))
+            if doc.get("workload", "resnext50_full_b8_1024") != workload or doc.get("source_sha256") != h:
+                continue
+            tot = n = 0
+            for k, v in doc["kernels"].items():
+                if any(w in k for w in want):
+                    tot += v["hbm_bytes_per_launch"] * v["dispatches"]
+                    n += v["dispatches"]
+            if n:
+                return round(tot / n)
     except Exception:
-        return None
+        pass
+    return None
 
 
 def build_model(backbone, device, seed=0, cls_scale=8.0):
@@ -190,19 +207,37 @@ def _time_config(workload, device, math, graph, rank, steps=20, warmup=3):
         images = torch.from_numpy(np.random.default_rng(1234 + rank).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(device)
         if graph:
             model.enable_graphs(True)
-        model(images, defer=graph)
-        torch.cuda.synchronize(device)
-        for _ in range(warmup):
-            model(images, defer=graph)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            model(images, defer=graph)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
-        return {"value": round(B * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
-                "steps": steps, "warmup": warmup, "per_gpu_batch": B, "height": H, "width": W, "hipgraph": bool(graph),
-                "dtype": ops.dtype_label()}
+
+        def run(defer):
+            """`steps` forwards between two synchronisations.  defer=False: every forward hands over the model's real
+            output list (under hipGraph: the ONE host read of the RoI level maxima + the two molding copies per
+            forward, the MoldBatch equivalent); defer=True: replays enqueued back to back, nothing read or molded."""
+            def one():
+                o = model(images, defer=defer)
+                return o
+            one()
+            torch.cuda.synchronize(device)
+            for _ in range(warmup):
+                one()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize(device)
+            return time.perf_counter() - t0
+
+        dt = run(False)
+        out = {"value": round(B * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
+               "steps": steps, "warmup": warmup, "per_gpu_batch": B, "height": H, "width": W, "hipgraph": bool(graph),
+               "dtype": ops.dtype_label()}
+        if graph:
+            # beside it: replays only (outputs deferred) -- the GPU-side cost of a forward when a serving loop overlaps the
+            # read of forward i with forward i + 1; NOT a complete forward (no molded roi_boxes / roi_masks are produced)
+            dte = run(True)
+            out["ms_per_step_replay_only"] = round(1e3 * dte / steps, 3)
+            out["note"] = ("ms_per_step / value: every forward returns the molded output list (host read of L ints + mold "
+                           "copies included); ms_per_step_replay_only: graph replays back to back, outputs never molded")
+        return out
     finally:
         ops.set_conv_math("f32")
         del model
@@ -233,16 +268,99 @@ def _time_oracle(fn, repeats, max_seconds, min_repeats=1):
     return times[len(times) // 2], len(times)
 
 
-def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, img, device, f16, quick, extra_modes=()):
+class _TorchCpuConvs:
+    """cpu_baseline ONLY (never the parity checker): for its duration the oracle's convolutions -- Conv2D, DepthwiseConv2D,
+    the ResNeXt grouped 3x3, Conv2DTranspose 2x2 s2 and max-pool, i.e. every op that is a loop of NumPy GEMMs / einsums in
+    oracle/tfops.py -- run through torch-CPU (oneDNN, channels-last, all threads) on the same weights and in the same
+    graph; GroupNorm, resize, crop_and_resize, box decode and NMS stay the oracle's NumPy.  This is what a competent CPU
+    forward of this network costs; kind: "port (torch-CPU convs)".  Exits restore the NumPy functions."""
+
+    def __enter__(self):
+        import numpy as np
+        import torch
+        import torch.nn.functional as F
+        from oracle import masklab as O
+        from oracle import tfops as T
+        self._saved = {(m, n): getattr(m, n) for m, n in ((T, "conv2d"), (T, "depthwise_conv2d"), (T, "max_pool"),
+                                                          (T, "conv2d_transpose_2x2_s2"), (O, "grouped_conv_fast"))}
+        wcache = {}
+
+        def nchw(x):                       # NHWC numpy -> NCHW view in channels-last memory (no copy)
+            return torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+
+        def nhwc(t):
+            return t.permute(0, 2, 3, 1).contiguous().numpy()
+
+        def weight(w, perm, groups_shape=None):
+            key = (id(w), perm)
+            if key not in wcache:
+                t = torch.from_numpy(np.ascontiguousarray(np.transpose(w, perm)).astype(np.float32))
+                if groups_shape is not None:
+                    t = t.reshape(groups_shape)
+                wcache[key] = (w, t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t)
+            return wcache[key][1]
+
+        def padded(x, kh, kw, stride, dilation, padding):
+            _, _, pt, pb, pl, pr = T._resolve_padding(x, kh, kw, stride, dilation, padding)
+            t = nchw(x.astype(np.float32, copy=False))
+            return F.pad(t, (pl, pr, pt, pb)) if (pt or pb or pl or pr) else t
+
+        def conv2d(x, w, b=None, stride=1, padding="same", dilation=1):
+            kh, kw, _, _ = w.shape
+            y = F.conv2d(padded(x, kh, kw, stride, dilation, padding), weight(w, (3, 2, 0, 1)),
+                         None if b is None else torch.from_numpy(np.asarray(b, np.float32)), stride=stride, dilation=dilation)
+            return nhwc(y)
+
+        def depthwise_conv2d(x, w, stride=1, padding="same", dilation=1):
+            kh, kw, cin, mult = w.shape
+            wt = weight(w, (2, 3, 0, 1), (cin * mult, 1, kh, kw))          # out channel = cin_idx * mult + m
+            return nhwc(F.conv2d(padded(x, kh, kw, stride, dilation, padding), wt, None, stride=stride, dilation=dilation,
+                                 groups=cin))
+
+        def grouped_conv_fast(x, dw_kernel, groups, c, stride):
+            # out[g*c+m] = sum_i conv(x[g*c+i], K[.., g*c+i, m]) = conv2d(groups) with weight[g*c+m, i] = K[.., g*c+i, m]
+            k = np.asarray(dw_kernel).reshape(3, 3, groups, c, c)           # [kh, kw, g, i, m]
+            wt = weight(dw_kernel, (0, 1, 2, 3))                            # (cache key only)
+            key = ("g", id(dw_kernel))
+            if key not in wcache:
+                wcache[key] = (dw_kernel, torch.from_numpy(np.ascontiguousarray(np.transpose(k, (2, 4, 3, 0, 1)))
+                                                           .reshape(groups * c, c, 3, 3).astype(np.float32))
+                               .contiguous(memory_format=torch.channels_last))
+            del wt
+            t = F.pad(nchw(x.astype(np.float32, copy=False)), (1, 1, 1, 1))
+            return nhwc(F.conv2d(t, wcache[key][1], None, stride=stride, groups=groups))
+
+        def conv2d_transpose_2x2_s2(x, w, b=None):
+            wt = weight(w, (3, 2, 0, 1))                                     # [cin, cout, 2, 2]
+            return nhwc(F.conv_transpose2d(nchw(x.astype(np.float32, copy=False)), wt,
+                                           None if b is None else torch.from_numpy(np.asarray(b, np.float32)), stride=2))
+
+        def max_pool(x, k=3, stride=2):
+            return nhwc(F.max_pool2d(nchw(x.astype(np.float32, copy=False)), k, stride))
+
+        T.conv2d, T.depthwise_conv2d, T.max_pool, T.conv2d_transpose_2x2_s2 = conv2d, depthwise_conv2d, max_pool, conv2d_transpose_2x2_s2
+        O.grouped_conv_fast = grouped_conv_fast
+        return self
+
+    def __exit__(self, *exc):
+        for (m, n), f in self._saved.items():
+            setattr(m, n, f)
+        return False
+
+
+def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, batch, device, f16, quick, extra_modes=()):
     """The oracle (the CPU restatement of the reference forward) as checker and as the timed CPU baseline.
-    img: uint8 [1,H,W,3] on the host (rank 0's first bench image).  -> (cpu_baseline, parity of the current conv math,
-    {mode: parity} for `extra_modes` -- the same oracle outputs, the GPU forward repeated under that mode)."""
+    batch: the bench batch, uint8 [B,H,W,3] on the device; the oracle runs its image 0, the GPU side of the parity check
+    runs the WHOLE batch in one forward (the launches bench.py times) and image 0 of that forward is compared.
+    -> (cpu_baseline, parity of the current conv math, {mode: parity} for `extra_modes` -- the same oracle outputs, the
+    GPU forward repeated under that mode)."""
     import numpy as np
     import torch
     from threadpoolctl import threadpool_info, threadpool_limits
     from oracle import fixtures as FX
     from oracle import masklab as O
     from oracle import metrics as OM
+    img = batch[:1].cpu().numpy()
     H, W = img.shape[1:3]
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
@@ -296,11 +414,35 @@ def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, img, dev
             samples["1x512x512 all threads"] = _time_oracle(lambda: oracle_forward(small), 5, 12.0, 3)
             with threadpool_limits(limits=1):
                 samples["1x512x512 1 thread"] = _time_oracle(lambda: oracle_forward(small), 5, 12.0, 3)
+    # ---- the same forward with its convolutions on torch-CPU (oneDNN): what a competent CPU implementation costs.  The
+    # patch lives in THIS leg only; the parity reference above came from the unpatched NumPy oracle.
+    torch_tag = "torch-CPU convs"
+    with _TorchCpuConvs():
+        oracle_forward()                                         # warm-up (oneDNN primitive caches, weight re-layouts)
+        k_all = f"{full} {torch_tag}, all threads"
+        samples[k_all] = (_time_oracle(oracle_forward, 1, 0.0) if quick else _time_oracle(oracle_forward, 5, 30.0, 3))
+        threads_of[k_all] = cores
+        if not quick:
+            for nt in (16, 1):
+                if nt >= cores:
+                    continue
+                torch.set_num_threads(nt)
+                try:
+                    with threadpool_limits(limits=nt):
+                        k_nt = f"{full} {torch_tag}, {nt} thread{'s' if nt > 1 else ''}"
+                        samples[k_nt] = _time_oracle(oracle_forward, 3, 30.0, 2 if nt == 1 else 3)
+                        threads_of[k_nt] = nt
+                finally:
+                    torch.set_num_threads(cores)
     best = min((k for k in samples if k.startswith(full)), key=lambda k: samples[k][0])
     dt, n_rep = samples[best]
-    cpu = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads_of[best], "kind": "port",
-           "sample": f"1 image {H}x{W}, full hot-path forward, NumPy/BLAS oracle-CPU (not TF-Keras), fastest thread "
-                     f"setting ({best.split(' ', 1)[1]}), median of {n_rep} after 1 warm-up, {dt:.1f}s each",
+    on_torch = torch_tag in best
+    cpu = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads_of[best],
+           "kind": "port (torch-CPU convs)" if on_torch else "port",
+           "sample": f"1 image {H}x{W}, full hot-path forward of the oracle (CPU restatement, not TF-Keras) "
+                     f"{'with its convolutions on torch-CPU / oneDNN' if on_torch else 'in NumPy / BLAS'}: fastest setting "
+                     f"({best.split(' ', 1)[1]}), median of {n_rep} after 1 warm-up, {dt:.2f}s each; the NumPy-only figures "
+                     f"are beside it in images_per_sec",
            "cpu_model": _cpu_model(), "host_cores": cores, "blas_threads": blas_threads,
            "images_per_sec": {k: round(1.0 / v[0], 4) for k, v in samples.items()},
            "seconds": {k: round(v[0], 2) for k, v in samples.items()},
@@ -315,7 +457,7 @@ def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, img, dev
     _, gap = FX.gap_threshold(ref["cls_pred"])
 
     def gpu_parity():
-        return _gpu_parity(cfg, model, w_fix, hot_weights, img, device, thr, ref, internals, stable, gap, scale, notes)
+        return _gpu_parity(cfg, model, w_fix, hot_weights, batch, device, thr, ref, internals, stable, gap, scale, notes)
 
     parity = gpu_parity()
     extra = {}
@@ -330,22 +472,36 @@ def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, img, dev
     return cpu, parity, extra
 
 
-def _gpu_parity(cfg, model, w_fix, hot_weights, img, device, thr, ref, internals, stable, gap, scale, notes):
-    """GPU side of the parity check under the current conv math: same weights, same threshold, the single image."""
+def _gpu_parity(cfg, model, w_fix, hot_weights, batch, device, thr, ref, internals, stable, gap, scale, notes):
+    """GPU side of the parity check under the current conv math: the WHOLE bench batch in one forward -- the same launch
+    shapes as the timed steps -- with the fixture's class-output kernels and threshold; image 0 of that forward is what
+    is compared with the oracle.  (The timed steps run with x8 class logits so that NMS and the mask head carry their
+    full load; only the class towers' output convs differ, so `timed_forward` additionally checks that loc_pred and
+    seg_pred of the x8-logit forward are BIT-identical to the checked forward's.)"""
     import numpy as np
     import torch
+    from oracle import fixtures as FX
     from oracle import metrics as OM
+    names = ["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"]
+    hot = dict(zip(names, model(batch)))                   # the timed configuration, as timed
+    hot_loc, hot_seg = hot["loc_pred"].clone(), hot["seg_pred"].clone()
+    del hot
     model.reload_class_outputs(w_fix)
     old_thr = model.detection_proposal.min_confidence
     model.detection_proposal.min_confidence = thr
     try:
-        got = [o.cpu().numpy() for o in model(torch.from_numpy(img).to(device), want_kept=True)]
+        outs = model(batch, want_kept=True)
         det0 = model.last_detections
+        timed_equal = bool(torch.equal(outs[1], hot_loc) and torch.equal(outs[4], hot_seg))
+        lcounts = det0["level_counts"].cpu().numpy()
         gpu_kept = det0["kept"][0, :int(det0["counts"][0])].cpu().numpy()
+        # image 0 of the batch, molded as the model molds it when it is run alone (reference misc.py:231-286)
+        # (only image 0 of the per-anchor / per-pixel tensors crosses PCIe; the RoI tensors are re-molded from the batch's)
+        got = FX.image_of_batch(names, [(o[:1] if n in ("cls_pred", "loc_pred", "seg_pred") else o).cpu().numpy()
+                                        for n, o in zip(names, outs)], lcounts, 0)
     finally:
         model.detection_proposal.min_confidence = old_thr
         model.reload_class_outputs(hot_weights)          # back to the timed configuration
-    names = ["cls_pred", "loc_pred", "roi_boxes", "roi_masks", "seg_pred"]
     got = dict(zip(names, got))
     diffs = {}
     for n in ("cls_pred", "loc_pred", "seg_pred", "roi_masks"):
@@ -365,7 +521,11 @@ def _gpu_parity(cfg, model, w_fix, hot_weights, img, device, thr, ref, internals
     # an unstable fixture is a FAILED parity leg, not a waiver of the order requirement
     ok = bool(all(v is not None and v <= 1e-3 for v in diffs.values()) and rows_exact and
               float(fm[0]) >= 0.999 and order_exact and stable == 8)
-    parity = {"image": "rank 0, image 0 of the bench batch", "tolerance": 1e-3,
+    ok = ok and timed_equal
+    parity = {"image": f"rank 0, image 0 of ONE {int(batch.shape[0])}-image forward (the timed launch shapes)", "tolerance": 1e-3,
+              "timed_forward": {"loc_pred_and_seg_pred_bit_identical_to_the_checked_forward": timed_equal,
+                                "note": "the timed steps differ from the checked forward only in the class towers' output "
+                                        "kernels (x8 logits: full NMS / mask-head load)"},
               "fixture": dict({"cls_logit_scale": scale, "min_confidence": thr, "threshold_gap": float(f"{gap:.3e}"),
                                "candidates": int((ref["cls_pred"] >= thr).sum()),
                                "max_score": round(float(ref["cls_pred"].max()), 4),
@@ -443,9 +603,9 @@ def main():
     pending = []                               # all-gathers in flight (consumed one step later)
 
     def step(collective=True):
-        # (under --graph the whole forward is one replay with no host read; `defer` keeps even the output molding's read
-        # out of the loop, so forwards are enqueued back to back)
-        outs = model(host_images.to(device, non_blocking=True) if args.host_inputs else images, defer=args.graph)
+        # (under --graph the whole forward is one replay; the model then reads the L per-level RoI maxima and molds
+        # roi_boxes / roi_masks -- the MoldBatch equivalent -- so every timed step yields the model's real output list)
+        outs = model(host_images.to(device, non_blocking=True) if args.host_inputs else images)
         mark("forward enqueued")
         if gather is not None and collective:
             if pending:                        # the previous batch's merged detections: make them visible to this stream
@@ -531,8 +691,7 @@ def main():
             per_kernel[k] = e
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]
-        # the committed PMC pass was taken on the default workload only
-        traffic = measured_traffic(dom) if args.workload == "resnext50_full_b8_1024" else None
+        traffic = measured_traffic(dom, args.workload)      # None unless a PMC pass of THIS workload on THESE sources is committed
         common = {"timing": "HIP events per launch, auxiliary streams off: each kernel alone on the chip",
                   "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                   "algorithmic_bytes_per_launch": round(1e6 * d["mbytes"] / d["launches"]),
@@ -600,7 +759,7 @@ def main():
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity, extra = cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, images[:1].cpu().numpy(),
+        cpu, parity, extra = cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, images,
                                                      device, f16, args.quick_cpu_baseline,
                                                      extra_modes=("f32x3",) if alt is not None else ())
         if alt is not None:
@@ -641,6 +800,9 @@ def main():
                        "detections_per_image_rank0": n_det, "nms_candidates_per_image_rank0": n_cand},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "f32x3": alt, "other_configs": others,
             "kernels": per_kernel,
+            # the ONE native library the product path loaded (masklab_hip/_lib.py: no override), and its sources' hash
+            "library": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "abi_version": int(_lib.load().ml_version()),
+                        "kernel_sources_sha256": csrc_hash()},
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -38,14 +38,16 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
 
-#define ML_ABI_VERSION 5              /* 2: ml_conv2d_desc gained `math` / `reserved0`
+#define ML_ABI_VERSION 6              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
                                             fp16 tensor storage
                                          4: fp16 storage in the heads: ML_MATH_F16S on the generic conv,
                                             ml_gn_desc.dtype, the *_f16 entry points of GroupNorm, resize,
                                             depthwise conv, global mean, RoI crop and the mask-head tail
                                          5: fixed-capacity RoI batches (`live`) in conv / GroupNorm / RoI crop /
-                                            mask-head tail descriptors, ml_mold_levels_f32                */
+                                            mask-head tail descriptors, ml_mold_levels_f32
+                                         6: ml_conv2d_launch_splits, ml_conv2d_gn_min_launch_tiles (reporting /
+                                            the size rule of gn_partials asked of the library, not restated by callers) */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -147,6 +149,14 @@ int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, int32_t has_w
  * 2 = the 256 x 256-tile kernel for half tensors with K >= 256 (conv1x1_h256.hip: the ResNeXt-101 stage 2-4 convs of
  * BASELINE configs[4]), 0 = neither (the generic implicit-GEMM kernel).  `tile` = 4 / 5 force 1 / 2 where they apply. */
 int ml_conv2d_uses_pipe(const ml_conv2d_desc *d);
+/* K slices (1 = not split) of every problem of the launch ml_conv2d_multi_f32 would make for these problems with a
+ * workspace of `workspace_bytes` (0 = none): launches of fewer than 192 tiles with a long K are cut along K, so a shard
+ * of a batch may sum K in other pieces than the whole batch does (fp32 rounding; reference DP merge
+ * engine/parallel.py:64-107).  splits: n host ints.  For reporting / tests. */
+int ml_conv2d_launch_splits(const ml_conv2d_desc *descs, int32_t n, int64_t workspace_bytes, int32_t *splits);
+/* Smallest launch, in 128 x 128 tiles over all its problems, that ml_conv2d_multi_f32 neither narrows to 128 x 64 / 128 x 32
+ * tiles nor cuts along K on the current device: the size from which ml_conv2d_desc.gn_partials may be set. */
+int64_t ml_conv2d_gn_min_launch_tiles(void);
 
 /* ResNeXt grouped 3x3 (reference engine/backbone/ResNext.py:212-219: DepthwiseConv2D(depth_multiplier=c)
  * + SplitGroups/ReduceGroups/MergeGroups), c = channels per group in {4,8,16}, C % 64 == 0, on

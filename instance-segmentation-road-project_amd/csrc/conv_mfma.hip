@@ -252,9 +252,12 @@ conv_mfma_kernel(const MultiArgs args) {                                        
     // (nobody reads those rows); rows of dead images inside a live tile are computed from whatever their input holds.
     if (p.live) {
         const int lim = max(1, *p.live);
-        const int i0 = fast_div(m0, P.div_howo) % p.live_period;
-        const int i1 = fast_div(min(m0 + BM, P.M) - 1, P.div_howo) % p.live_period;
-        if (i0 >= lim && i1 >= lim && i0 <= i1) return;
+        // decided on ABSOLUTE image indices: the tile's images a0..a1 are all dead iff they lie in ONE period (then their
+        // slots are i0..i1 with i1 - i0 == a1 - a0) and the first slot is already past the limit.  (A tile of three or
+        // more small images can cross a period boundary with i0 <= i1: slot 0 of the next image is live.)
+        const int a0 = fast_div(m0, P.div_howo), a1 = fast_div(min(m0 + BM, P.M) - 1, P.div_howo);
+        const int i0 = a0 % p.live_period, i1 = a1 % p.live_period;
+        if (i0 >= lim && a1 - a0 == i1 - i0) return;
     }
 
     const int tid = threadIdx.x;
@@ -1043,8 +1046,49 @@ int choose_splits(long long tiles, int chunks) {
     return s < 2 ? 1 : s;
 }
 
-// split_tiles >= 0: the tile count the split-K decision is taken on (see narrow_tile_for_small_launch), else this
-// launch's own
+// host copy of the kernel's out_vec_ok(): the fast (float4, LDS-transposed) epilogue -- the only one that writes gn_partials
+static bool host_out_vec_ok(const ml_conv2d_desc &p) {
+    const int co = p.shuffle2x2 ? (p.cout >> 2) : p.cout;
+    bool ok = (co % 4 == 0) && (p.out_cstride % 4 == 0) && (p.out_coff % 4 == 0) && (p.out_bstride % 4 == 0) && ml_aligned16(p.out);
+    if (p.bias) ok = ok && ml_aligned16(p.bias);
+    if (p.residual) ok = ok && (p.res_cstride % 4 == 0) && (p.res_coff % 4 == 0) && ml_aligned16(p.residual);
+    return ok;
+}
+
+// The K-slice count of every problem of one launch on BM x BN tiles with KC-deep chunks -- THE place the decision is taken
+// (launch_multi and the reporting entry ml_conv2d_launch_splits both call it).  split_tiles >= 0: the tile count the
+// decision is taken on (see narrow_tile_for_small_launch), else this launch's own.  Split-K looks at the whole launch:
+// five pyramid levels of one image are 171 tiles together -- a third of the chip -- and each tile then walks all 36
+// chunks alone (92 us); slicing K fills the other CUs.  Fixed-capacity RoI batches (`live`): an image's RoIs are spread
+// over the launch's RoI levels, so about 1 / levels of the nominal tiles are live -- the decision is taken on that
+// estimate (the host does not know the counts).
+static void plan_splits(const ml_conv2d_desc *descs, int n, int BM, int BN, int KC, bool have_ws, long long ws_bytes,
+                        long long split_tiles, int *splits_out, int *cps_out = nullptr) {
+    long long launch_tiles = 0, ws_off = 0;
+    int n_live = 0;
+    for (int i = 0; i < n; ++i) n_live += descs[i].live != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
+        const long long t = ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
+        launch_tiles += descs[i].live ? (t + n_live - 1) / n_live : t;
+    }
+    if (split_tiles >= 0) launch_tiles = split_tiles;
+    for (int i = 0; i < n; ++i) {
+        const ml_conv2d_desc &d = descs[i];
+        const long long M = (long long)d.B * d.Ho * d.Wo;
+        const long long MB = (M + BM - 1) / BM;
+        const int chunks = d.KH * d.KW * (d.span_pad / KC);
+        int splits = have_ws ? choose_splits(launch_tiles, chunks) : 1;     // (the reduce kernel stores half too)
+        const long long slab_bytes = (long long)splits * MB * BM * d.n_pad * 4;
+        if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
+        const int cps = (chunks + splits - 1) / splits;
+        splits = (chunks + cps - 1) / cps;           // drop empty trailing slices
+        if (splits > 1) ws_off += (slab_bytes + 255) / 256 * 256;
+        splits_out[i] = splits;
+        if (cps_out) cps_out[i] = cps;
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false, int NSTAGE = 2>
 int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long ws_bytes, hipStream_t s,
                  long long split_tiles = -1) {
@@ -1064,19 +1108,8 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
     MultiArgs args;
     args.n = n;
     long long start = 0, ws_off = 0;
-    // split-K looks at the whole launch: five pyramid levels of one image are 171 tiles together -- a third of
-    // the chip -- and each tile then walks all 36 chunks alone (92 us); slicing K fills the other CUs
-    // Fixed-capacity RoI batches (`live`): an image's RoIs are spread over the launch's RoI levels, so about 1 / levels
-    // of the nominal tiles are live -- the split decision is taken on that estimate (the host does not know the counts).
-    long long launch_tiles = 0;
-    int n_live = 0;
-    for (int i = 0; i < n; ++i) n_live += descs[i].live != nullptr;
-    for (int i = 0; i < n; ++i) {
-        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
-        const long long t = ((M + BM - 1) / BM) * (descs[i].n_pad / BN);
-        launch_tiles += descs[i].live ? (t + n_live - 1) / n_live : t;
-    }
-    if (split_tiles >= 0) launch_tiles = split_tiles;
+    int planned[MAXP], planned_cps[MAXP];
+    plan_splits(descs, n, BM, BN, KC, workspace != nullptr, ws_bytes, split_tiles, planned, planned_cps);
     for (int i = 0; i < n; ++i) {
         const ml_conv2d_desc &d = descs[i];
         Problem &P = args.p[i];
@@ -1093,16 +1126,17 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         P.wgt_bytes = (unsigned)((long long)d.n_pad * P.ktot * ES);
         const int chunks = d.KH * d.KW * P.ncpt;
         P.blocks_per_split = (P.MB + 7) / 8 * 8 * P.NB;
-        int splits = workspace ? choose_splits(launch_tiles, chunks) : 1;     // (the reduce kernel stores half too)
+        const int splits = planned[i];
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
-        if (splits > 1 && ws_off + slab_bytes > ws_bytes) splits = 1;
         if (d.gn_partials)
             ML_REQUIRE(GNS && splits == 1 && BN == 128 && d.cout == 128 && d.n_pad == 128 && M % BM == 0 && !d.residual &&
-                           !d.out_bstride && !d.out_f16 && !d.shuffle2x2 && d.act != ML_ACT_SIGMOID && !d.live,
-                       "conv2d: gn_partials needs a launch that is neither narrowed nor split along K (>= 257 tiles of 128 x 128), "
-                       "cout = 128, whole 128-row tiles, a dense fp32 destination and no residual");
-        P.cps = (chunks + splits - 1) / splits;
-        P.splits = (chunks + P.cps - 1) / P.cps;     // drop empty trailing slices
+                           !d.out_bstride && !d.out_f16 && !d.shuffle2x2 && d.act != ML_ACT_SIGMOID && !d.live &&
+                           host_out_vec_ok(d),
+                       "conv2d: gn_partials needs a launch that is neither narrowed nor split along K (ml_conv2d_gn_min_launch_tiles() "
+                       "tiles of 128 x 128), cout = 128, whole 128-row tiles, no residual, and a dense fp32 destination on the "
+                       "vector epilogue (out / bias 16-byte aligned, out_cstride and out_coff multiples of 4)");
+        P.splits = splits;
+        P.cps = planned_cps[i];
         P.slab = nullptr;
         if (P.splits > 1) {
             P.slab = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ws_off);
@@ -1194,6 +1228,9 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
             continue;
         }
         if (d.live) return -2;          // (image groups would renumber the images a `live` period counts)
+        // gn_partials is indexed by the problem's 128-row tile: a group starts at tile b0 * Ho * Wo / 128 of the whole
+        // tensor, which must be a whole number for every group
+        if (d.gn_partials && (per * d.Ho * d.Wo) % 128) return -3;
         const long long in_img = (long long)d.H * d.W * d.in_cstride;
         const long long out_pix = d.shuffle2x2 ? 4ll * d.Ho * d.Wo : (long long)d.Ho * d.Wo;
         const long long out_img = d.out_bstride ? d.out_bstride : out_pix * d.out_cstride;
@@ -1205,6 +1242,7 @@ static int split_by_image_groups(const ml_conv2d_desc *descs, int n, ml_conv2d_d
             g.in = reinterpret_cast<const float *>(reinterpret_cast<const char *>(d.in) + b0 * in_img * es_in);
             g.out = reinterpret_cast<float *>(reinterpret_cast<char *>(d.out) + b0 * out_img * es_out);
             if (d.residual) g.residual = d.residual + b0 * res_img;
+            if (d.gn_partials) g.gn_partials = d.gn_partials + (b0 * d.Ho * d.Wo / 128) * 8;   // [tile][4 waves][sum, sum of squares]
             out[m++] = g;
         }
     }
@@ -1300,6 +1338,7 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     ml_conv2d_desc split[MAXP];
     const int n = split_by_image_groups(descs_in, n_in, split, MAXP);
     ML_REQUIRE(n != -2, "conv2d: a problem with `live` images must stay below 2 GiB of activations");
+    ML_REQUIRE(n != -3, "conv2d: gn_partials on an activation >= 2 GiB needs image groups of whole 128-row tiles");
     ML_REQUIRE(n >= 1, "conv2d: too many >= 2 GiB activations in one launch (more than %d image groups)", MAXP);
     const ml_conv2d_desc *descs = split;
     int t0 = 0;
@@ -1375,6 +1414,30 @@ extern "C" int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, in
     long long ref_tiles = -1;
     const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles));
     return x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
+}
+
+// K slices per problem of the launch ml_conv2d_multi_f32 would make for these problems (1 = not split; the persistent
+// 1x1 kernels never split).  splits: n ints.  For reporting / tests: which launches cut their K sum differently when
+// the batch changes.  ML_OK, or ML_E_BADARG.
+extern "C" int ml_conv2d_launch_splits(const ml_conv2d_desc *descs, int32_t n, int64_t workspace_bytes, int32_t *splits) {
+    ML_REQUIRE(descs && splits && n >= 1 && n <= MAXP, "conv2d_launch_splits: need 1..%d problems", MAXP);
+    for (int i = 0; i < n; ++i) splits[i] = 1;
+    if (n == 1 && ml_conv2d_uses_pipe(descs)) return ML_OK;
+    const int t0 = pick_tile(descs[0].cout, descs[0].tile);
+    long long ref_tiles = -1;
+    const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, workspace_bytes > 0, &ref_tiles));
+    const int BM = x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
+    const int BN = t == 1 ? 128 : (t == 2 ? 64 : 32);
+    const int KC = descs[0].math == ML_MATH_F16S ? 64 : 32;
+    plan_splits(descs, n, BM, BN, KC, workspace_bytes > 0, workspace_bytes, ref_tiles, splits);
+    return ML_OK;
+}
+
+// Smallest launch (in 128 x 128 tiles, all problems together) that ml_conv2d_multi_f32 neither narrows to 128 x 64 / 128 x 32
+// tiles nor cuts along K on THIS device -- the size from which ml_conv2d_desc.gn_partials may be used.
+extern "C" int64_t ml_conv2d_gn_min_launch_tiles(void) {
+    const long long narrow_below = ml_resident_blocks(2) / 2 + 1;      // (blocks * 2 <= resident -> 128 x 64 tiles)
+    return narrow_below > 192 ? narrow_below : 192;                    // (choose_splits: no K slices from 192 tiles)
 }
 
 extern "C" int ml_conv2d_f32(const ml_conv2d_desc *dp, void *stream) {

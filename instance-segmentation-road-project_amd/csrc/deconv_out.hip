@@ -184,7 +184,9 @@ deconv_out_kernel(const DoArgs A) {
                 const int last = min(m0t + TM, (int)P.M) - 1;
                 const int r0 = div_small(m0t, P.hw, P.r_hw), r1 = div_small(last, P.hw, P.r_hw);
                 const int j0 = r0 - div_small(r0, P.n_l, P.r_nl) * P.n_l, j1 = r1 - div_small(r1, P.n_l, P.r_nl) * P.n_l;
-                if (j0 >= lim && j1 >= lim && j0 <= j1) continue;
+                // all RoIs r0..r1 of the tile are dead iff they sit in ONE image (slots j0..j1, j1 - j0 == r1 - r0) whose
+                // first slot here is already past the limit (a tile spanning >= 3 RoIs may cross into the next image)
+                if (j0 >= lim && r1 - r0 == j1 - j0) continue;
             }
             L.pi = pi;
             L.m0 = m0t;

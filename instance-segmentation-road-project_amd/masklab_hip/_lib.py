@@ -7,10 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MASKLAB_HIP_LIB overrides the library file (A/B benchmarking of kernel variants)
-LIB_PATH = os.environ.get("MASKLAB_HIP_LIB") or os.path.join(_HERE, "libmasklab_hip.so")
+# The ONE library the product path loads: the in-tree build.  No environment override -- an experiment that wants another
+# build assigns `_lib.LIB_PATH` in its own script before the first load() (scripts/h256_ab.py); bench.py prints the
+# resolved path into its JSON line.
+LIB_PATH = os.path.join(_HERE, "libmasklab_hip.so")
 
-ABI_VERSION = 5          # ML_ABI_VERSION of include/masklab_hip.h
+ABI_VERSION = 6          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -69,6 +71,8 @@ SIGNATURES = {
     "ml_conv2d_uses_pipe": (C.c_int, [C.POINTER(ConvDesc)]),
     "ml_conv2d_launch_ntile": (C.c_int, [C.POINTER(ConvDesc), _i32, _i32]),
     "ml_conv2d_launch_mtile": (C.c_int, [C.POINTER(ConvDesc), _i32, _i32]),
+    "ml_conv2d_launch_splits": (C.c_int, [C.POINTER(ConvDesc), _i32, _i64, C.POINTER(C.c_int32)]),
+    "ml_conv2d_gn_min_launch_tiles": (_i64, []),
     "ml_conv2d_workspace_bytes": (_i64, []),
     "ml_conv2d_multi_f32": (C.c_int, [C.POINTER(ConvDesc), _i32, _vp, _i64, _vp]),
     "ml_deconv2x2_out1x1_f32": (C.c_int, [C.POINTER(DeconvOutProblem), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

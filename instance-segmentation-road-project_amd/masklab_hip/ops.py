@@ -13,13 +13,31 @@ import torch
 from . import _lib
 from .packing import PackedConv, resolve_padding
 
+import weakref
+
 _ws_cache = {}
-_ws_retired = []     # superseded scratch buffers stay allocated: a captured hipGraph may still hold their addresses
+_ws_retired = []     # superseded scratch buffers stay allocated WHILE some model holds a captured hipGraph (which may
+                     # replay with their addresses); released once the last graph owner has dropped its graphs
+_graph_owners = weakref.WeakSet()
+
+
+def graph_owner_registered(model):
+    _graph_owners.add(model)
+
+
+def graph_owner_released(model):
+    """A model dropped its captured graphs: with no owner left nothing can replay with a retired buffer's address."""
+    _graph_owners.discard(model)
+    if not len(_graph_owners):
+        _ws_retired.clear()
 
 # When set to a list, every launcher appends {"kernel", "flops", "bytes", "start", "end"} with
 # torch.cuda.Event pairs recorded on the launch stream (bench.py's roofline leg).  `bytes` /
 # `flops` are ALGORITHMIC: inputs read once + outputs written once (+ weights once), 2*MACs.
 PROFILE = None
+# When set to a list, every dense-conv launch appends (shape label, K slices per problem) as the library reports them
+# (ml_conv2d_launch_splits): tests use it to name the launches whose K sum is cut differently when the batch changes.
+LAUNCH_LOG = None
 
 
 class _Prof:
@@ -224,6 +242,8 @@ def _conv_desc(x, dc, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE, r
         _require_dev(gn_partials, "gn_partials")
         if gn_partials.dtype != torch.float64 or gn_partials.numel() < 8 * ((B * Ho * Wo + 127) // 128):
             raise ValueError("conv2d: gn_partials must be a float64 tensor of 4 x 2 values per 128-row tile")
+        if d.out_coff % 4 or d.out_cstride % 4:        # only the vector epilogue writes the partial sums
+            raise ValueError("conv2d: gn_partials needs a destination slice aligned to 4 channels")
         d.gn_partials = gn_partials.data_ptr()
     if live is not None:               # (device int32 tensor [1], slots per image): a fixed-capacity RoI batch
         lv, period = live
@@ -259,15 +279,35 @@ def _conv_kernel_name(p, descs=None, n=1, half=False):
 def gn_fusable(out_shape, C_out, groups, dc, launch_tiles, dtype):
     """Can the GroupNormalization behind this conv take its statistics from the conv's epilogue (ml_conv2d_desc.gn_partials)?
     out_shape = (B, Ho, Wo): whole 128-row tiles per image and per chunk, one 128-wide N tile, fp32, and a launch big
-    enough that the library neither narrows its tiles nor cuts K (>= 257 tiles of 128 x 128 in all).
+    enough that the library neither narrows its tiles nor cuts K (ml_conv2d_gn_min_launch_tiles(): 257 tiles of 128 x 128 in
+    all on a 256-CU part).
     -> (sum, sum of squares) pairs per chunk (4 per tile: one per wave), or 0."""
     B, Ho, Wo = out_shape
     hw = Ho * Wo
     p = dc.p
     ok = (CONV_MATH in ("f32", "f32x3") and dtype == torch.float32 and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
           not p.shuffle2x2 and not p.group_cin_step and hw % 128 == 0 and hw % groups == 0 and (hw // groups) % 128 == 0 and
-          launch_tiles >= 257)
+          launch_tiles >= _gn_min_launch_tiles())
     return 4 * ((hw // groups) // 128) if ok else 0
+
+
+_GN_MIN_TILES = None
+
+
+def _gn_min_launch_tiles():
+    """The launch size from which the LIBRARY neither narrows the tiles nor cuts K on this device (asked once; not a
+    constant of this file: it follows the device's compute-unit count)."""
+    global _GN_MIN_TILES
+    if _GN_MIN_TILES is None:
+        _GN_MIN_TILES = int(_lib.load().ml_conv2d_gn_min_launch_tiles())
+    return _GN_MIN_TILES
+
+
+def _log_launch(arr, n, ws, label):
+    if LAUNCH_LOG is not None:
+        sp = (C.c_int32 * n)()
+        _lib.check(_lib.load().ml_conv2d_launch_splits(arr, n, ws.numel(), sp), "ml_conv2d_launch_splits")
+        LAUNCH_LOG.append((label, tuple(int(v) for v in sp)))
 
 
 def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT_NONE,
@@ -289,6 +329,7 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
         which = lib.ml_conv2d_uses_pipe(C.byref(d))          # 1: the 128 x 128 pipelined kernel, 2: the half 256 x 256 one
         if which:
             name = "conv1x1_h256_h" if which == 2 else ("conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe")
+    _log_launch(C.byref(d), 1, ws, shape)
     with _Prof(name, flops, nbytes, shape):
         _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret
@@ -304,16 +345,18 @@ def conv2d_multi(problems):
     if n > 12:
         return conv2d_multi(problems[:12]) + conv2d_multi(problems[12:])
     arr = (_lib.ConvDesc * n)()
-    rets, flops, nbytes = [], 0.0, 0.0
+    rets, flops, nbytes, shapes = [], 0.0, 0.0, []
     for i, pr in enumerate(problems):
         pr = dict(pr)
-        d, ret, (f, nb, _shape) = _conv_desc(pr.pop("x"), pr.pop("dc"), **pr)
+        d, ret, (f, nb, shape) = _conv_desc(pr.pop("x"), pr.pop("dc"), **pr)
         arr[i] = d
         rets.append(ret)
         flops += f
         nbytes += nb
+        shapes.append(shape)
     name = _conv_kernel_name(problems[0]["dc"].p, arr, n, half=problems[0]["x"].dtype == torch.float16)
     ws = workspace(int(lib.ml_conv2d_workspace_bytes()), problems[0]["x"].device, "conv")
+    _log_launch(arr, n, ws, " | ".join(shapes))
     with _Prof(name, flops, nbytes, f"multi x{n}"):
         _lib.check(lib.ml_conv2d_multi_f32(arr, n, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return rets

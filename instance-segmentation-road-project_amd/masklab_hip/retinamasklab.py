@@ -138,6 +138,7 @@ class InferenceModel(K.Layer):
         # the outputs are handed over (ONE read, after the whole forward is enqueued).  True / False / "auto" = with
         # hipGraph replay (the whole forward is then ONE graph), where nothing but that read remains for the host.
         self.device_counts = "auto"
+        self._capacity_held = 0          # bytes of capacity tensors already captured in this model's graphs (they count as free)
         self._build_shapes()
 
     # ---- structure
@@ -195,9 +196,17 @@ class InferenceModel(K.Layer):
         seeded by weight name so the result is independent of construction order."""
         return K.init_weights(self.weight_specs(), seed)
 
+    def _drop_graphs(self):
+        """Forget the captured graphs (their private memory pools go with them) and let ops release the scratch buffers
+        that only those captures kept alive."""
+        from . import ops
+        self._graphs = {}
+        self._capacity_held = 0
+        ops.graph_owner_released(self)
+
     def load_weights(self, weights, device="cuda"):
         self.device = torch.device(device)
-        self._graphs = {}                    # captured graphs hold the addresses of the tensors being replaced
+        self._drop_graphs()                  # captured graphs hold the addresses of the tensors being replaced
         for l in self.layers:
             l.load_weights(weights, self.device)
         return self
@@ -207,7 +216,7 @@ class InferenceModel(K.Layer):
         move the score distribution; everything else keeps its device copy)."""
         if self.detection_networks is None:
             raise RuntimeError("no detection networks")
-        self._graphs = {}
+        self._drop_graphs()
         for block in self.detection_networks[2].blocks:
             block[-1].load_weights(weights, self.device)
 
@@ -338,14 +347,36 @@ class InferenceModel(K.Layer):
                 roi_masks = mask_subnet(roi_fmaps)
                 outputs += [roi_boxes, roi_masks]
                 self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"],
-                                            boxes=st["boxes"], payload=st["payload"])
+                                            boxes=st["boxes"], payload=st["payload"],
+                                            level_counts=st["lcounts"], level_max=st["lmax"])
         self._join_side(st)
         if self.semantic_networks is not None:
             outputs.append(st["seg_pred"])
         return outputs
 
     # ---- stage 2 at capacity: no host read inside the forward
-    MAX_CAPACITY_ROIS = 8192            # B x nms_max_output_size above which the capacity tensors are not worth their memory
+    # The capacity form trades memory for the missing host read: every RoI level is sized for B x nms_max_output_size slots.
+    # It is used while its tensors stay below CAPACITY_BYTES_LIMIT and a quarter of the device's free memory (each input
+    # shape captured under hipGraph keeps its own set: graph-private pools are not shared), and never past
+    # MAX_CAPACITY_ROIS slots per level.
+    MAX_CAPACITY_ROIS = 8192
+    CAPACITY_BYTES_LIMIT = 16 << 30
+
+    def capacity_bytes(self, batch):
+        """Estimate of what ONE fixed-capacity stage 2 holds: per RoI level the crops and every tower / deconv
+        intermediate ([B*cap, ch, cw, C] each: under graph capture none of them is recycled), plus masks_cap
+        [B, L*cap, 2ch, 2cw, classes] fp32 and the split-K workspace (per stream)."""
+        from . import ops
+        ins = self.configuration.instance
+        pra, mask = self.instance_networks[2], self.instance_networks[3]
+        cap = int(self.detection_proposal.nms_max_output_size)
+        L = ins.max_k + 1
+        ch, cw = pra.crop_size
+        es = 2 if ops.half_storage() else 4
+        slots = int(batch) * cap
+        per_level = slots * ch * cw * mask.num_features * es * (2 + mask.num_depth)
+        masks = slots * L * 4 * ch * cw * mask.num_classes * 4
+        return L * per_level + masks + 2 * int(ops._lib.load().ml_conv2d_workspace_bytes())
 
     def _capacity_wanted(self, images):
         mode = getattr(self, "device_counts", "auto")
@@ -354,8 +385,14 @@ class InferenceModel(K.Layer):
             return False
         pra, mask = self.instance_networks[2], self.instance_networks[3]
         cap = int(self.detection_proposal.nms_max_output_size)
-        return (mask.capacity_supported(tuple(pra.crop_size)) and int(images.shape[0]) * cap <= self.MAX_CAPACITY_ROIS
-                and cap * pra.crop_size[0] * pra.crop_size[1] >= 128)
+        if not (mask.capacity_supported(tuple(pra.crop_size)) and int(images.shape[0]) * cap <= self.MAX_CAPACITY_ROIS
+                and cap * pra.crop_size[0] * pra.crop_size[1] >= 128):
+            return False
+        need = self.capacity_bytes(int(images.shape[0]))
+        limit = self.CAPACITY_BYTES_LIMIT
+        if self.device is not None and self.device.type == "cuda":
+            limit = min(limit, torch.cuda.mem_get_info(self.device)[0] // 4 + self._capacity_held)
+        return need <= limit
 
     def _stage2_capacity(self, st):
         """RoI crops + mask head with every level at capacity (reference engine/layers/instance.py:115-134,211-233 +
@@ -366,7 +403,7 @@ class InferenceModel(K.Layer):
             st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"], st["lmax"])
         masks_cap = mask_subnet(roi_fmaps, lives=lives)
         self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"], boxes=st["boxes"],
-                                    payload=st["payload"])
+                                    payload=st["payload"], level_counts=st["lcounts"], level_max=st["lmax"])
         self._join_side(st)
         return dict(cls_pred=st["cls_pred"], loc_pred=st["loc_pred"], boxes_cap=boxes_cap, masks_cap=masks_cap,
                     lmax=st["lmax"], cap=int(st["proposed"].shape[1]), seg_pred=st.get("seg_pred"))
@@ -386,10 +423,13 @@ class InferenceModel(K.Layer):
         """Capture the forward (~300 kernel launches) into a hipGraph per input shape and replay it: one launch instead
         of hundreds, which is what a batch-1 forward is bound by.  With the fixed-capacity stage 2 (`device_counts`) the
         WHOLE forward is one graph; otherwise stage 1 is (stage 2's shapes then depend on a host read).  The tensors
-        the graph returns are graph-owned buffers, valid until the next call (`outputs_graph_owned`)."""
+        the graph returns are graph-owned buffers, valid until the next call (`outputs_graph_owned`).
+        Memory: every captured input shape (x conv math x thresholds) keeps its own activations, capacity tensors
+        (`capacity_bytes`) and split-K workspace for as long as the graph lives; `enable_graphs(False)`, `load_weights`
+        and `reload_class_outputs` drop them all.  A server that sees many input shapes should bucket them."""
         self._use_graphs = bool(enabled)
         if not enabled:
-            self._graphs = {}
+            self._drop_graphs()
         return self
 
     @property
@@ -424,6 +464,9 @@ class InferenceModel(K.Layer):
             finally:
                 self._capturing_whole = False
             entry = self._graphs[key] = (graph, static_in, st)
+            ops.graph_owner_registered(self)
+            if whole:
+                self._capacity_held += self.capacity_bytes(int(images.shape[0]))
         graph, static_in, st = entry
         static_in.copy_(images)
         graph.replay()
@@ -598,6 +641,33 @@ def load_masklab_inference_model_from_weights(weights, config: ModelConfiguratio
         with np.load(weights) as z:
             weights = {k: z[k] for k in z.files}
     _, inference = construct_masklab_networks(config)
+    inference.load_weights(weights, device)
+    return construct_deploy_network(config, inference)
+
+
+def load_masklab_inference_model_from_h5(save_path, config: ModelConfiguration, serving=False, device="cuda"):
+    """Same name and arguments as reference engine/retinamasklab.py:498-643: the checkpoint at `save_path` -> the deploy
+    model `images uint8 [B,H,W,3] -> (detection, instance, semantic)` (DownSampleInput -> inference network ->
+    TrimInstances / SemanticSmoothing / ResizeLike -> UpSampleOutput).  `save_path`: a Keras .h5 as the reference
+    writes it (needs `h5py`, imported lazily; the layer-name re-wiring of :515-586 becomes masklab_hip/checkpoint.py's
+    name mapping) or the .npz tools/convert_keras_h5.py makes of it.  The networks are built from `config` (the
+    reference rebuilds them from the loaded Keras model; `config.json` saved beside the weights, engine/train.py:31-32,
+    is that configuration).  serving=True puts DecodeImageContent (JPEG bytes in, misc.py:328-337) in front -- image I/O,
+    outside this library: decode on the host and call the serving=False model."""
+    if serving:
+        raise NotImplementedError("load_masklab_inference_model_from_h5(serving=True) wraps the model in "
+                                  "DecodeImageContent (JPEG byte strings in): image decoding is outside the accelerated "
+                                  "path -- decode on the host and use the serving=False model (or construct_serving_network "
+                                  "for the summary outputs)")
+    _, inference = construct_masklab_networks(config)
+    path = str(save_path)
+    if path.lower().endswith(".npz"):
+        with np.load(path) as z:
+            weights = {k: z[k] for k in z.files}
+    else:
+        from . import checkpoint
+        specs = {k: tuple(v.shape) for k, v in inference.weight_specs().items()}
+        weights = checkpoint.load_keras_h5(path, specs)
     inference.load_weights(weights, device)
     return construct_deploy_network(config, inference)
 

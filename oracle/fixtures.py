@@ -87,3 +87,26 @@ def choose_logit_scale(config, cls_pred_scale1, loc_pred, H, W, grid=None, trial
         if same == trials and len(kept) > 0:
             best = (float(s), thr)
     return best
+
+
+def image_of_batch(names, outs, level_counts, b):
+    """The model's output list for a BATCH -> what the same model returns for image `b` ALONE.
+    roi_boxes / roi_masks are concatenations over the RoI levels of MoldBatch-ed tensors whose second axis is
+    max(1, max over the batch of the level's RoI count) (reference engine/layers/instance.py:127-138,
+    misc.py:231-286): an image run alone keeps max(1, its own count) rows of every level.
+    names: model.output_names; outs: numpy arrays; level_counts: int [B, L] (model.last_detections["level_counts"])."""
+    level_counts = np.asarray(level_counts)
+    n_batch = [max(1, int(v)) for v in level_counts.max(axis=0)]
+    n_own = [max(1, int(v)) for v in level_counts[b]]
+    rows, off = [], 0
+    for nb, no in zip(n_batch, n_own):
+        rows += list(range(off, off + no))
+        off += nb
+    one = []
+    for name, o in zip(names, outs):
+        if name in ("roi_boxes", "roi_masks"):
+            assert o.shape[1] == off, (name, o.shape, off)
+            one.append(o[b:b + 1][:, rows])
+        else:
+            one.append(o[b:b + 1])
+    return one

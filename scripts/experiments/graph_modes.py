@@ -7,23 +7,30 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "instance-segmentation-road-project_amd
 import numpy as np, torch
 import bench
 from masklab_hip import ops
-dev = torch.device("cuda", 0)
-cfg, model, w, hot = bench.build_model("resnext50", dev)
-images = torch.from_numpy(np.random.default_rng(1234).integers(0, 256, (8, 1024, 1024, 3), dtype=np.uint8)).to(dev)
-def run(label, steps=20):
-    for _ in range(4): model(images)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(steps): model(images)
-    torch.cuda.synchronize()
-    print(f"{label:40s} {1e3 * (time.perf_counter() - t) / steps:7.3f} ms", flush=True)
-for math in ("f32", "f32x3"):
-    ops.set_conv_math(math)
-    model.enable_graphs(False); model.device_counts = "auto"
-    run(f"{math} eager")
-    model.enable_graphs(True); model.device_counts = False
-    run(f"{math} stage-1 graph + eager stage 2")
-    model.enable_graphs(True); model.device_counts = "auto"
-    run(f"{math} whole graph")
-    model.enable_graphs(False)
-ops.set_conv_math("f32")
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    cfg, model, w, hot = bench.build_model("resnext50", dev)
+    images = torch.from_numpy(np.random.default_rng(1234).integers(0, 256, (8, 1024, 1024, 3), dtype=np.uint8)).to(dev)
+    def run(label, steps=20):
+        for _ in range(4): model(images)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps): model(images)
+        torch.cuda.synchronize()
+        print(f"{label:40s} {1e3 * (time.perf_counter() - t) / steps:7.3f} ms", flush=True)
+    for math in ("f32", "f32x3"):
+        ops.set_conv_math(math)
+        model.enable_graphs(False); model.device_counts = "auto"
+        run(f"{math} eager")
+        model.enable_graphs(True); model.device_counts = False
+        run(f"{math} stage-1 graph + eager stage 2")
+        model.enable_graphs(True); model.device_counts = "auto"
+        run(f"{math} whole graph")
+        model.enable_graphs(False)
+    ops.set_conv_math("f32")
+
+
+if __name__ == "__main__":
+    main()

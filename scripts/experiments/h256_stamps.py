@@ -16,34 +16,40 @@ lib = os.path.join(OUT, "libmasklab_hip_stamps.so")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DH256_STAMPS", "-I" + os.path.join(ROOT, "include"),
        "-shared", "-o", lib] + [os.path.join(CSRC, f) for f in srcs]
 subprocess.run(cmd, check=True)
-os.environ["MASKLAB_HIP_LIB"] = lib
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instance-segmentation-road-project_amd")]
 import numpy as np
 import torch
 from masklab_hip import _lib, ops, packing
 
-ops.set_conv_math("f16s")
-rng = np.random.default_rng(0)
-for label, (B, H, W), cin, cout, res in [("conv1 1024->512", (16, 80, 80), 1024, 512, False),
-                                          ("conv3 512->1024 +res", (16, 80, 80), 512, 1024, True),
-                                          ("s4 2048->1024", (16, 40, 40), 2048, 1024, False)]:
-    x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float16)).cuda()
-    w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
-    r = torch.from_numpy(rng.normal(size=(B, H, W, cout)).astype(np.float16)).cuda() if res else None
-    dc = ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32), tile=5), "cuda")
-    for _ in range(3):
-        out = ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
-    e.record()
-    torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (256 * 8 * 4))()
-    rc = _lib.load().ml_debug_h256_stamps(buf)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 4).astype(np.float64)
-    tiles = a[..., 3].mean()
-    nk = cin // 64
-    print(f"{label:24s} {1e3 * s.elapsed_time(e):7.1f} us  tiles/block {tiles:.2f}  per chunk: wait+barrier {a[..., 0].mean() / tiles / nk:7.0f} "
-          f"mfma phase {a[..., 1].mean() / tiles / nk:7.0f} cycles (ideal 2048 per SIMD pair: 1024 per wave x 2 waves)  "
-          f"epilogue per tile {a[..., 2].mean() / tiles:8.0f} cycles; s_memtime ticks, max over waves wait {a[..., 0].max() / tiles / nk:7.0f}")
+_lib.LIB_PATH = lib          # the stamped build (experiments select their library here; the product has no override)
+
+def main():
+    ops.set_conv_math("f16s")
+    rng = np.random.default_rng(0)
+    for label, (B, H, W), cin, cout, res in [("conv1 1024->512", (16, 80, 80), 1024, 512, False),
+                                              ("conv3 512->1024 +res", (16, 80, 80), 512, 1024, True),
+                                              ("s4 2048->1024", (16, 40, 40), 2048, 1024, False)]:
+        x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float16)).cuda()
+        w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        r = torch.from_numpy(rng.normal(size=(B, H, W, cout)).astype(np.float16)).cuda() if res else None
+        dc = ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32), tile=5), "cuda")
+        for _ in range(3):
+            out = ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, residual=r, out=out)
+        e.record()
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * (256 * 8 * 4))()
+        rc = _lib.load().ml_debug_h256_stamps(buf)
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 4).astype(np.float64)
+        tiles = a[..., 3].mean()
+        nk = cin // 64
+        print(f"{label:24s} {1e3 * s.elapsed_time(e):7.1f} us  tiles/block {tiles:.2f}  per chunk: wait+barrier {a[..., 0].mean() / tiles / nk:7.0f} "
+              f"mfma phase {a[..., 1].mean() / tiles / nk:7.0f} cycles (ideal 2048 per SIMD pair: 1024 per wave x 2 waves)  "
+              f"epilogue per tile {a[..., 2].mean() / tiles:8.0f} cycles; s_memtime ticks, max over waves wait {a[..., 0].max() / tiles / nk:7.0f}")
+
+
+if __name__ == "__main__":
+    main()

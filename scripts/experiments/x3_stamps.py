@@ -1,21 +1,30 @@
 # Experiment helper for the s_memtime stamps patch of the 256 x 128 f32x3 kernel: per chunk, the cycles one wave spends in its
 # two MFMA phases, in the counted wait before the barrier and at the barrier (the stamped build writes them one row past the
-# output, which this script pads).  MASKLAB_HIP_LIB=<stamped .so> python scripts/experiments/x3_stamps.py
+# output, which this script pads).  EXPERIMENT_LIB=<stamped .so> python scripts/experiments/x3_stamps.py
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instance-segmentation-road-project_amd")]
 import numpy as np, torch
 from masklab_hip import _lib, ops, packing
-ops.set_conv_math("f32x3")
-rng = np.random.default_rng(0)
-for label, (B, H, W), cin, cout, k in [("tower 3x3 256->256 P3", (8, 128, 128), 256, 256, 3), ("s3 conv1 1024->512", (8, 64, 64), 1024, 512, 1),
-                                       ("mask 3x3 256->256 x800", (800, 14, 14), 256, 256, 3)]:
-    x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
-    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
-    dc = ops.DeviceConv(packing.pack_dense(w, None), "cuda")
-    vt = torch.zeros(B * H * W * cout + 4096, device="cuda")          # the stamps land one row past the output
-    for _ in range(3):
-        ops.conv2d(x, dc, padding="same", out_view=(vt, 0, cout, H * W * cout))
-    torch.cuda.synchronize()
-    d = vt[B * H * W * cout:B * H * W * cout + 4].cpu().numpy()
-    print(f"{label:26s} chunks {int(d[3]):3d}: MFMA phases {d[0]:7.0f} cycles/chunk, counted wait {d[1]:6.0f}, barrier {d[2]:6.0f}", flush=True)
+if os.environ.get("EXPERIMENT_LIB"):
+    _lib.LIB_PATH = os.environ["EXPERIMENT_LIB"]      # (read by this script only; the product path has no override)
+
+
+def main():
+    ops.set_conv_math("f32x3")
+    rng = np.random.default_rng(0)
+    for label, (B, H, W), cin, cout, k in [("tower 3x3 256->256 P3", (8, 128, 128), 256, 256, 3), ("s3 conv1 1024->512", (8, 64, 64), 1024, 512, 1),
+                                           ("mask 3x3 256->256 x800", (800, 14, 14), 256, 256, 3)]:
+        x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
+        w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+        dc = ops.DeviceConv(packing.pack_dense(w, None), "cuda")
+        vt = torch.zeros(B * H * W * cout + 4096, device="cuda")          # the stamps land one row past the output
+        for _ in range(3):
+            ops.conv2d(x, dc, padding="same", out_view=(vt, 0, cout, H * W * cout))
+        torch.cuda.synchronize()
+        d = vt[B * H * W * cout:B * H * W * cout + 4].cpu().numpy()
+        print(f"{label:26s} chunks {int(d[3]):3d}: MFMA phases {d[0]:7.0f} cycles/chunk, counted wait {d[1]:6.0f}, barrier {d[2]:6.0f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,7 @@
 corrected per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
 bytes of wide (16 B/lane) coalesced streaming reads -> x2; WRITE_SIZE is exact for 16 B/lane streaming stores;
 other access patterns are to be calibrated on a known byte count (FETCH_FACTOR_1 below).
-Usage: pmc_traffic.py fetch_results.db write_results.db out.json"""
+Usage: pmc_traffic.py fetch_results.db write_results.db out.json [workload]"""
 import json
 import os
 import sqlite3
@@ -48,6 +48,7 @@ def main():
     json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); gfx950 FETCH correction x2 for every "
                          "kernel (calibrated on no-reuse 1 GiB copies in this code's access patterns: "
                          "profiles/r03_calib_pmc_fetch.md, scripts/calibrate/calib.hip)",
+               "workload": sys.argv[4] if len(sys.argv) > 4 else "resnext50_full_b8_1024",
                "source_sha256": csrc_hash(), "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]:
         print(f"{k[:80]:80s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch x {v['dispatches']}")

@@ -31,6 +31,6 @@ for pass in fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_CYCLES,GRBM
   python3 scripts/rocpd_pmc_summary.py $(find $OUT/pmc_$name -name "*.db" | head -1) $OUT/pmc_$name.md > /dev/null
   echo "pmc $name done"
 done
-python3 scripts/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $OUT/traffic.json
+python3 scripts/pmc_traffic.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $OUT/traffic.json $WL
 grep '^{' $OUT/bench_trace.log | tail -1 > $OUT/bench_line.json
 rm -rf $OUT/trace $OUT/trace_c $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma     # the SQLite results are large; the summaries are what travels back

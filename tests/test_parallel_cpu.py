@@ -76,6 +76,91 @@ def test_all_gather_detections_gloo_world2():
     np.testing.assert_array_equal(s0[:, 0, 0, 0], [0, 0, 1, 1])
 
 
+def _worker8(rank, world, port, q):
+    """BASELINE configs[3]'s exact record: 8 ranks x B_local = 8 images, capacity 100 -> [8, 601] floats per rank."""
+    import torch.distributed as dist
+    from masklab_hip import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, cap = 8, 100
+        g = torch.Generator().manual_seed(1000 + rank)
+        counts = torch.randint(0, cap + 1, (B,), generator=g, dtype=torch.int32)
+        counts[rank % B] = 0                                     # an image without detections on every rank
+        prop = torch.full((B, cap, 6), -1.0)
+        for b in range(B):
+            n = int(counts[b])
+            prop[b, :n] = torch.rand((n, 6), generator=g) * 1000.0
+            prop[b, :n, 4] = torch.randint(0, 5, (n,), generator=g).float()
+        payload = parallel.pack_payload(prop, counts)
+        assert tuple(payload.shape) == (8, 601)
+        gather = parallel.AsyncDetectionGather("cpu")
+        handles = [gather.launch(payload, cap) for _ in range(3)]          # bench.py keeps one in flight per step
+        for h in handles:
+            vp, vc = gather.wait(h)
+            assert tuple(vp.shape) == (64, cap, 6) and tuple(vc.shape) == (64,) and vc.dtype == torch.int32
+            assert parallel.check_merged(vp, vc, prop, counts, rank, world) is None
+            assert parallel.check_merged(vp, vc, prop, counts, (rank + 1) % world, world) is not None
+        q.put((rank, vc.numpy().copy(), vp[:, 0, :].numpy().copy(), counts.numpy().copy(), prop[:, 0, :].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_detections_gloo_world8_config3_record_shape():
+    """The N = 8 path on CPU (no 8-GPU node is available to this build): eight gloo ranks, each with the per-GPU record of
+    BASELINE configs[3] -- B_local = 8, nms_max_output_size = 100, payload [8, 601] -- through AsyncDetectionGather and
+    check_merged.  Every rank must see the same 64-image merge with rank r's images at offset 8 r (the reference's
+    Concatenate(axis=0), engine/parallel.py:64-66,92-107)."""
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, vc, first_rows, counts, own_first = q.get(timeout=240)
+        res[rank] = (vc, first_rows, counts, own_first)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[r][0], res[0][0])               # every rank holds the same merge
+        np.testing.assert_array_equal(res[r][1], res[0][1])
+    for r in range(world):                                                # ... rank r's record at image offset 8 r
+        np.testing.assert_array_equal(res[0][0][8 * r:8 * r + 8], res[r][2])
+        np.testing.assert_array_equal(res[0][1][8 * r:8 * r + 8], res[r][3])
+
+
+def test_bench_binds_local_rank_device_and_refuses_missing_gpus():
+    """`bench.py --gpus 8`: every rank binds cuda:<LOCAL_RANK> BEFORE it creates the RCCL group with that device, a rank
+    without a GPU of its own exits, and the spawner refuses to run when fewer than N GPUs are visible (no GPU here: the
+    refusal is exercised for real, the binding is read from the source)."""
+    import ast
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    src = root.joinpath("bench.py").read_text()
+    main = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    text = ast.unparse(main)
+    i_rank = text.index("local_rank = int(os.environ.get('LOCAL_RANK', '0'))")
+    i_guard = text.index("local_rank >= torch.cuda.device_count()")
+    i_bind = text.index("torch.cuda.set_device(dev_index)")
+    i_group = text.index("dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)")
+    assert i_rank < i_guard < i_bind < i_group
+    assert "dev_index = 0 if rehearsal else local_rank" in text
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASKLAB_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 8" in (r.stderr + r.stdout) and "refusing" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())        # no JSON line from fewer devices
+
+
 def test_single_process_passthrough_and_shard_errors():
     from masklab_hip import parallel
     p, c = torch.zeros(2, 3, 6), torch.zeros(2, dtype=torch.int32)
