@@ -54,8 +54,9 @@ struct H256Args {
     long long M;
     int K, N;
     int in_cs, in_coff, out_cs, out_coff;    // elements; the residual shares out_cs / out_coff
-    int panels, G, gshift;                   // 256-row panels; N tiles per panel = G = 1 << gshift
-    int step;                                // panels worked on at the same time = grid >> gshift
+    int G, gshift;                           // N tiles = G = 1 << gshift
+    int nb;                                  // row ranges = blocks per N tile = grid >> gshift
+    int g_base, g_rem;                       // 32-row groups per range: g_base, the first g_rem ranges one more
     int xcd_map;
     float lo, hi;
     int clamp;
@@ -73,6 +74,10 @@ __device__ __forceinline__ unsigned records_left(long long off, long long total)
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void *ptr, long long off, long long total) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)ptr + off), 0, (int)records_left(off, total), 0x00020000);
+}
+// `nbytes` bytes from ptr + off (the rows of ONE tile: anything past them reads zeros / is not stored, no traffic)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_span(const void *ptr, long long off, int nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)ptr + off), 0, nbytes, 0x00020000);
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -132,20 +137,28 @@ conv1x1_h256_kernel(const H256Args A) {
     const int scr_r = (t_row * SCR_LD + t_col) * 4;
 
     const int nk = A.K / 64;
-    const long long in_total = A.M * (long long)A.in_cs * 2;
-    const long long out_total = A.M * (long long)A.out_cs * 2;
     const long long w_total = (long long)A.N * A.K * 2;
 
-    // ---- which tiles: one N tile (group) for the block's life, panels panel0, panel0 + step, ...
+    // ---- which rows: one N tile for the block's life and ONE contiguous range of rows, cut at multiples of 32 so that
+    // all ranges of a launch differ by at most 32 rows (a 1x1 conv's rows are independent: where the cut falls changes no
+    // result).  The range is walked in 256-row tiles; its last tile may be partial -- a launch of 3.125 tile rounds then
+    // costs 3 rounds and a 32-row tail instead of 4 rounds (round 3: whole 256-row panels dealt round-robin).
     const int bid = (int)blockIdx.x;
     const int gmask = A.G - 1;
-    const int slot = bid >> 3, ppx = A.step >> 3;
+    const int slot = bid >> 3, ppx = A.nb >> 3;
     const int nt = A.xcd_map ? (slot & gmask) : (bid & gmask);
-    int panel = A.xcd_map ? (bid & 7) * ppx + (slot >> A.gshift) : (bid >> A.gshift);
-    if (panel >= A.panels) return;
+    const int ri = A.xcd_map ? (bid & 7) * ppx + (slot >> A.gshift) : (bid >> A.gshift);
+    const int g0 = ri * A.g_base + min(ri, A.g_rem);
+    const int gcnt = A.g_base + (ri < A.g_rem ? 1 : 0);
+    long long row = (long long)g0 * 32;
+    const long long row_end = min((long long)(g0 + gcnt) * 32, A.M);
+    if (row >= row_end) return;
+    int rows = (int)min((long long)TM, row_end - row);
 
     const __amdgpu_buffer_rsrc_t rb = rsrc_at(A.wgt, (long long)nt * TN * A.K * 2, w_total);
-    auto res_a = [&](int p) { return rsrc_at(A.in, (long long)p * TM * A.in_cs * 2, p < A.panels ? in_total : 0); };
+    auto res_a = [&](long long r0, int nrows) {              // rows r0 .. r0 + nrows - 1 of the input (nrows = 0: empty)
+        return rsrc_span(A.in, nrows > 0 ? r0 * A.in_cs * 2 : 0, nrows * A.in_cs * 2);
+    };
     auto stage = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rbb, char *buf, int soff) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(ra, buf + (64 * i + 8 * wave) * ROWB, a_voff[i], soff);
@@ -163,75 +176,87 @@ conv1x1_h256_kernel(const H256Args A) {
             bias[ni][k] = A.bias ? *reinterpret_cast<const f32x4 *>(A.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    __amdgpu_buffer_rsrc_t ra = res_a(panel);
+    __amdgpu_buffer_rsrc_t ra = res_a(row, rows);
     stage(ra, rb, lds, 0);                                      // chunk 0 of the first tile
     int buf = 0;
     bool pre = false;                 // chunk 1 of the current tile was issued before the previous tile's epilogue
     for (;;) {
-        const int next_panel = panel + A.step;
-        const __amdgpu_buffer_rsrc_t ra_next = res_a(next_panel);      // (empty past the end: no traffic)
+        const long long next_row = row + TM;
+        const int next_rows = next_row < row_end ? (int)min((long long)TM, row_end - next_row) : 0;
+        const bool has_next = next_rows > 0;
+        const __amdgpu_buffer_rsrc_t ra_next = res_a(next_row, next_rows);      // (empty past the end: no traffic)
+        // 32-row sub-tiles of this wave that exist in the tile (4 in a whole tile; the last tile of a range may be short)
+        const int lm = min(4, max(0, (rows - wr * 128 + 31) >> 5));
         f32x16 acc[4][2];
-        for (int kc = 0; kc < nk; ++kc) {
-            // My share of this chunk has landed.  Vector-memory operations retire in issue order, so what may stay in
-            // flight is counted: behind chunk 0 of a `pre` tile sit chunk 1's 8 loads and the previous tile's 16 stores
-            // (with a residual its loads, already waited for, retired everything older than the stores); behind chunk 1
-            // only those stores -- the store drain of a tile (128 KB per CU at ~10 B/clk) overlaps the next tile's first
-            // two chunks instead of stalling its first wait.
-            if (pre && kc == 0) {
-                if constexpr (HAS_RES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            } else if (pre && kc == 1) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();                               // ... everyone's; and the other buffer is free
-            const char *rd = lds + buf * BUFB;
-            char *wrb = lds + (buf ^ 1) * BUFB;
-            const bool do_dma = !(pre && kc == 0);                      // (chunk 1 of a `pre` tile is already in flight)
-            const bool more = kc + 1 < nk;
-            const __amdgpu_buffer_rsrc_t ra_nx = more ? ra : ra_next;
-            const __amdgpu_buffer_rsrc_t rb_nx = (more || next_panel < A.panels) ? rb : rsrc_at(A.wgt, 0, 0);
-            const int soff = more ? (kc + 1) * ROWB : 0;
-            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0 .. 7
-            f32x4 fa[2][4], fb[2][2];
-            auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) {
-                const int slot16 = ((ks * 2 + h) ^ swz) * 16;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd + a_off + m * 32 * ROWB + slot16);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4 *>(rd + b_off + n * 32 * ROWB + slot16);
-            };
-            read_frags(0, fa[0], fb[0]);
-            if (kc == 0) {                                             // a tile's chains start from 0 (once per tile)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-            }
-            static_for<0, 32>([&](auto ic) {
-                constexpr int idx = decltype(ic)::value;               // ks * 8 + mi * 2 + ni
-                constexpr int ks = idx >> 3, mi = (idx >> 1) & 3, ni = idx & 1;
-                if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-                const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
-                if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
-                    constexpr int p = idx;                              // piece 0..7
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (do_dma) {
-                        if constexpr (p < 4) lds_dma16(ra_nx, wrb + (64 * p + 8 * wave) * ROWB, a_voff[p], soff);
-                        else lds_dma16(rb_nx, wrb + (TM + 64 * (p - 4) + 8 * wave) * ROWB, b_voff[p - 4], soff);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        // ONE instruction stream for whole and short tiles: every MFMA sits behind a wave-uniform test of its sub-tile
+        // (scalar compare + branch that falls through in a whole tile).  A second, unconditional copy of the loop for
+        // whole tiles made the compiler keep the accumulators in scratch memory (964-1048 spilled registers): not an option.
+        {
+            constexpr bool FULL = false;
+            for (int kc = 0; kc < nk; ++kc) {
+                // My share of this chunk has landed.  Vector-memory operations retire in issue order, so what may stay in
+                // flight is counted: behind chunk 0 of a `pre` tile sit chunk 1's 8 loads and the previous tile's 16 stores
+                // (with a residual its loads, already waited for, retired everything older than the stores); behind chunk 1
+                // only those stores -- the store drain of a tile (128 KB per CU at ~10 B/clk) overlaps the next tile's first
+                // two chunks instead of stalling its first wait.
+                if (pre && kc == 0) {
+                    if constexpr (HAS_RES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                } else if (pre && kc == 1) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-            });
-            buf ^= 1;
+                __builtin_amdgcn_s_barrier();                               // ... everyone's; and the other buffer is free
+                const char *rd = lds + buf * BUFB;
+                char *wrb = lds + (buf ^ 1) * BUFB;
+                const bool do_dma = !(pre && kc == 0);                      // (chunk 1 of a `pre` tile is already in flight)
+                const bool more = kc + 1 < nk;
+                const __amdgpu_buffer_rsrc_t ra_nx = more ? ra : ra_next;
+                const __amdgpu_buffer_rsrc_t rb_nx = (more || has_next) ? rb : rsrc_at(A.wgt, 0, 0);
+                const int soff = more ? (kc + 1) * ROWB : 0;
+                // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0 .. 7
+                f32x4 fa[2][4], fb[2][2];
+                auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) __attribute__((always_inline)) {
+                    const int slot16 = ((ks * 2 + h) ^ swz) * 16;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd + a_off + m * 32 * ROWB + slot16);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4 *>(rd + b_off + n * 32 * ROWB + slot16);
+                };
+                read_frags(0, fa[0], fb[0]);
+                if (kc == 0) {                                             // a tile's chains start from 0 (once per tile)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+                }
+                static_for<0, 32>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value;               // ks * 8 + mi * 2 + ni
+                    constexpr int ks = idx >> 3, mi = (idx >> 1) & 3, ni = idx & 1;
+                    if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                    if (FULL || mi < lm) {
+                        const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+                    }
+                    if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
+                        constexpr int p = idx;                              // piece 0..7
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (do_dma) {
+                            if constexpr (p < 4) lds_dma16(ra_nx, wrb + (64 * p + 8 * wave) * ROWB, a_voff[p], soff);
+                            else lds_dma16(rb_nx, wrb + (TM + 64 * (p - 4) + 8 * wave) * ROWB, b_voff[p - 4], soff);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                buf ^= 1;
+            }
         }
         // chunk 1 of the NEXT tile goes out before this tile's stores (its buffer, the last chunk's, is free once every
         // wave has read its fragments): see the counted waits above
-        pre = next_panel < A.panels && nk >= 2;
+        pre = has_next && nk >= 2;
         if (pre) {
             __builtin_amdgcn_s_barrier();
             stage(ra_next, rb, lds + (buf ^ 1) * BUFB, ROWB);
@@ -239,29 +264,25 @@ conv1x1_h256_kernel(const H256Args A) {
 
         // ---- epilogue of this tile (the next tile's first chunk is already on its way).  Four groups (mi) of four
         // 16-row x 32-column pieces; the residual of group g + 1 is fetched (inline asm, counted waits) before group g's
-        // stores are issued, so no load ever waits for a store.
-        const long long tile_off = ((long long)panel * TM * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
-        const __amdgpu_buffer_rsrc_t ro = rsrc_at(A.out, tile_off, out_total);
-        const i32x4 rr = rsrc_words(A.res, tile_off, HAS_RES ? out_total : 0);
+        // stores are issued, so no load ever waits for a store.  Rows past the tile's own are neither read nor stored
+        // (resource extents); a short tile -- always the last of its range -- skips the groups that do not exist.
+        const long long tile_off = (row * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
+        const int tile_bytes = rows * A.out_cs * 2 - (A.out_coff + nt * TN) * 2;
+        const __amdgpu_buffer_rsrc_t ro = rsrc_span(A.out, tile_off, tile_bytes);
+        const unsigned long long rbase = (unsigned long long)((const char *)A.res + (HAS_RES ? tile_off : 0));
+        const i32x4 rr = {(int)(unsigned)rbase, (int)((unsigned)(rbase >> 32) & 0xffffu), HAS_RES ? tile_bytes : 0, 0x00020000};
         float *sw = reinterpret_cast<float *>(scratch + scr_w);
         const f32x4 *sr = reinterpret_cast<const f32x4 *>(scratch + scr_r);
         auto voff_of = [&](int mi, int ni, int hs) {
             return ((wr * 128 + mi * 32 + hs * 16 + t_row) * A.out_cs + wc * 64 + ni * 32 + t_col) * 2;
         };
         f32x4 rq[2][4];
-        auto load_group = [&](int mi, f32x4 (&q)[4]) {
+        auto load_group = [&](int mi, f32x4 (&q)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = buf_load16_asm(rr, voff_of(mi, k >> 1, k & 1));
         };
-        if constexpr (HAS_RES) load_group(0, rq[0]);
-        static_for<0, 4>([&](auto mc) {
+        auto store_group = [&](auto mc, f32x4 (&q)[4]) __attribute__((always_inline)) {
             constexpr int mi = decltype(mc)::value;
-            if constexpr (HAS_RES) {
-                if constexpr (mi < 3) load_group(mi + 1, rq[(mi + 1) & 1]);
-                // younger than this group's loads: the next group's 4 loads and the previous group's 4 stores
-                constexpr int younger = (mi < 3 ? 4 : 0) + (mi > 0 ? 4 : 0);
-                wait_loaded4<younger>(rq[mi & 1][0], rq[mi & 1][1], rq[mi & 1][2], rq[mi & 1][3]);
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ni = k >> 1, hs = k & 1;
@@ -273,7 +294,7 @@ conv1x1_h256_kernel(const H256Args A) {
                 }
                 f32x4 v0 = sr[0], v1 = sr[1];
                 if constexpr (HAS_RES) {
-                    const f16x8 rh = __builtin_bit_cast(f16x8, rq[mi & 1][k]);
+                    const f16x8 rh = __builtin_bit_cast(f16x8, q[k]);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { v0[c] += (float)rh[c]; v1[c] += (float)rh[4 + c]; }
                 }
@@ -290,9 +311,35 @@ conv1x1_h256_kernel(const H256Args A) {
                                  (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, voff_of(mi, ni, hs), 0, 0);
             }
-        });
-        if (next_panel >= A.panels) break;
-        panel = next_panel;
+        };
+        if (rows == TM) {
+            if constexpr (HAS_RES) load_group(0, rq[0]);
+            static_for<0, 4>([&](auto mc) {
+                constexpr int mi = decltype(mc)::value;
+                if constexpr (HAS_RES) {
+                    if constexpr (mi < 3) load_group(mi + 1, rq[(mi + 1) & 1]);
+                    // younger than this group's loads: the next group's 4 loads and the previous group's 4 stores
+                    constexpr int younger = (mi < 3 ? 4 : 0) + (mi > 0 ? 4 : 0);
+                    wait_loaded4<younger>(rq[mi & 1][0], rq[mi & 1][1], rq[mi & 1][2], rq[mi & 1][3]);
+                }
+                store_group(mc, rq[mi & 1]);
+            });
+        } else {
+            // the short last tile: nothing follows it, so its groups need no pipelining -- load, wait for everything, store
+            static_for<0, 4>([&](auto mc) {
+                constexpr int mi = decltype(mc)::value;
+                if (mi < lm) {
+                    if constexpr (HAS_RES) {
+                        load_group(mi, rq[0]);
+                        wait_loaded4<0>(rq[0][0], rq[0][1], rq[0][2], rq[0][3]);
+                    }
+                    store_group(mc, rq[0]);
+                }
+            });
+        }
+        if (!has_next) break;
+        row = next_row;
+        rows = next_rows;
         ra = ra_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -337,15 +384,18 @@ int ml_conv1x1_h256_try(const ml_conv2d_desc &d, hipStream_t s, int *took) {
     A.in = d.in; A.wgt = d.wgt; A.bias = d.bias; A.res = d.residual; A.out = d.out;
     A.M = M; A.K = d.span; A.N = d.cout;
     A.in_cs = d.in_cstride; A.in_coff = d.in_coff; A.out_cs = d.out_cstride; A.out_coff = d.out_coff;
-    A.panels = (int)((M + TM - 1) / TM);
+    const int panels = (int)((M + TM - 1) / TM);
     A.G = d.cout / 256;
     A.gshift = 0;
     while ((1 << A.gshift) < A.G) ++A.gshift;
     const int resident = ml_resident_blocks(1);                  // one 8-wave block per CU (256 on MI355X; a multiple of 32)
-    const long long units = (long long)A.panels * A.G;
-    int grid = units < resident ? (int)units : resident / A.G * A.G;
+    const long long units = (long long)panels * A.G;
+    const int grid = units < resident ? (int)units : resident / A.G * A.G;
     A.xcd_map = (A.G > 1 && grid % (8 * A.G) == 0) ? 1 : 0;
-    A.step = grid >> A.gshift;
+    A.nb = grid >> A.gshift;                                      // row ranges: every block gets the same rows +- 32
+    const long long groups32 = (M + 31) / 32;
+    A.g_base = (int)(groups32 / A.nb);
+    A.g_rem = (int)(groups32 % A.nb);
     A.clamp = d.act != ML_ACT_NONE;
     A.lo = 0.f;
     A.hi = d.act == ML_ACT_RELU6 ? 6.f : 3.402823466e38f;

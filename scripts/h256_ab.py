@@ -27,6 +27,8 @@ SHAPES = [
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--lib":        # an experiment build (the product path has no override)
+        _lib.LIB_PATH = os.path.abspath(sys.argv[2])
     ops.set_conv_math("f16s")
     rng = np.random.default_rng(0)
     reps = 10

@@ -46,7 +46,10 @@ def test_bench_json_contract_single_rank():
     assert 0 < d["roofline"]["frac"] < 1
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
-    assert d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_baseline"]["kind"] in ("port", "port (torch-CPU convs)")        # the oracle, NumPy-only or with oneDNN convs
+    assert any("torch-CPU convs" in k for k in d["cpu_baseline"]["images_per_sec"])   # both ways are timed and reported
+    assert d["parity"]["timed_forward"]["loc_pred_and_seg_pred_bit_identical_to_the_checked_forward"] is True
+    assert d["library"]["path"].endswith("masklab_hip/libmasklab_hip.so") and d["library"]["abi_version"] == 6
     for key in ("cpu_model", "blas_threads", "images_per_sec"):
         assert key in d["cpu_baseline"], key
     assert any("1 thread" in k for k in d["cpu_baseline"]["images_per_sec"])
