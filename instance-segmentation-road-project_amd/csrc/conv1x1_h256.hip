@@ -39,10 +39,11 @@ namespace {
 
 constexpr int TM = 256, TN = 256;                  // block tile
 constexpr int ROWB = 128;                          // bytes of K per staged row and chunk (64 halves)
-constexpr int BUFB = (TM + TN) * ROWB;             // one staging buffer: 64 KB
+constexpr int ABUF = TM * ROWB, BBUF = TN * ROWB;  // one chunk of the A tile / of the B tile: 32 KB each
 constexpr int SCR_LD = 36;                         // floats per row of a wave's transposition scratch
-constexpr int SCRB = 16 * SCR_LD * 4;
-constexpr int H256_LDS = 2 * BUFB + 8 * SCRB;      // 149 504 B
+constexpr int SCRB = 16 * SCR_LD * 4;              // (8 waves x 2 304 B: lives in the A slot the tile's last chunk freed)
+constexpr int H256_LDS = 3 * ABUF + 2 * BBUF;      // 163 840 B = all of a CU's LDS: a ring of 3 A slots + 2 B slots
+static_assert(8 * SCRB <= ABUF, "the epilogue scratch must fit an A slot");
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -127,12 +128,12 @@ conv1x1_h256_kernel(const H256Args A) {
         a_voff[i] = ((ld_r + 64 * i) * A.in_cs + A.in_coff) * 2 + ld_g * 16;
         b_voff[i] = (ld_r + 64 * i) * A.K * 2 + ld_g * 16;
     }
-    const int a_off = (wr * 128 + r) * ROWB;                   // fragment rows of this lane
-    const int b_off = TM * ROWB + (wc * 64 + r) * ROWB;
+    const int a_off = (wr * 128 + r) * ROWB;                   // fragment rows of this lane, inside an A slot / a B slot
+    const int b_off = (wc * 64 + r) * ROWB;
+    char *const lds_b = lds + 3 * ABUF;                        // [A slot 0][A slot 1][A slot 2][B slot 0][B slot 1]
 
     // ---- epilogue ownership inside a 16-row x 32-column piece: lane -> row lane >> 2, columns 8 (lane & 3) .. + 7
     const int t_row = lane >> 2, t_col = (lane & 3) * 8;
-    char *scratch = lds + 2 * BUFB + wave * SCRB;
     const int scr_w = (4 * h * SCR_LD + r) * 4;
     const int scr_r = (t_row * SCR_LD + t_col) * 4;
 
@@ -141,8 +142,7 @@ conv1x1_h256_kernel(const H256Args A) {
 
     // ---- which rows: one N tile for the block's life and ONE contiguous range of rows, cut at multiples of 32 so that
     // all ranges of a launch differ by at most 32 rows (a 1x1 conv's rows are independent: where the cut falls changes no
-    // result).  The range is walked in 256-row tiles; its last tile may be partial -- a launch of 3.125 tile rounds then
-    // costs 3 rounds and a 32-row tail instead of 4 rounds (round 3: whole 256-row panels dealt round-robin).
+    // result).  The range is walked in 256-row tiles; the last may be short (rows past it read zeros and are not stored).
     const int bid = (int)blockIdx.x;
     const int gmask = A.G - 1;
     const int slot = bid >> 3, ppx = A.nb >> 3;
@@ -156,14 +156,17 @@ conv1x1_h256_kernel(const H256Args A) {
     int rows = (int)min((long long)TM, row_end - row);
 
     const __amdgpu_buffer_rsrc_t rb = rsrc_at(A.wgt, (long long)nt * TN * A.K * 2, w_total);
+    const __amdgpu_buffer_rsrc_t r_none = rsrc_at(A.wgt, 0, 0);         // empty extent: the request is counted, nothing moves
     auto res_a = [&](long long r0, int nrows) {              // rows r0 .. r0 + nrows - 1 of the input (nrows = 0: empty)
         return rsrc_span(A.in, nrows > 0 ? r0 * A.in_cs * 2 : 0, nrows * A.in_cs * 2);
     };
-    auto stage = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rbb, char *buf, int soff) {
+    auto stage_a = [&](__amdgpu_buffer_rsrc_t ra, char *dst, int soff) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(ra, buf + (64 * i + 8 * wave) * ROWB, a_voff[i], soff);
+        for (int i = 0; i < 4; ++i) lds_dma16(ra, dst + (64 * i + 8 * wave) * ROWB, a_voff[i], soff);
+    };
+    auto stage_b = [&](__amdgpu_buffer_rsrc_t rbb, char *dst, int soff) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(rbb, buf + (TM + 64 * i + 8 * wave) * ROWB, b_voff[i], soff);
+        for (int i = 0; i < 4; ++i) lds_dma16(rbb, dst + (64 * i + 8 * wave) * ROWB, b_voff[i], soff);
     };
 
     // bias of this wave's 64 columns, in the epilogue's column ownership: 2 sub-tiles x 8 floats
@@ -176,96 +179,98 @@ conv1x1_h256_kernel(const H256Args A) {
             bias[ni][k] = A.bias ? *reinterpret_cast<const f32x4 *>(A.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+    // ---- the chunk stream.  Chunk c of the block (tiles back to back, nk chunks each) reads A slot c % 3 and B slot c % 2.
+    // While it is computed the block requests B of chunk c + 1 and A of chunk c + 2: the activations -- which come from
+    // beyond L2 and need ~2 us under load -- fly for two chunk times, the weights (L2 hits) for one.  With two 64 KB
+    // buffers (round 3) at most 64 KB per CU were in flight, and 64 KB per ~2.2 us is exactly the ~29 GB/s per CU that
+    // kernel stood at; here it is 64 KB of A + 32 KB of B.  Vector-memory operations retire in issue order, so every wait is
+    // a COUNT of what may stay in flight behind the requests that are needed.
     __amdgpu_buffer_rsrc_t ra = res_a(row, rows);
-    stage(ra, rb, lds, 0);                                      // chunk 0 of the first tile
-    int buf = 0;
-    bool pre = false;                 // chunk 1 of the current tile was issued before the previous tile's epilogue
+    stage_b(rb, lds_b, 0);                                             // B(0)
+    stage_a(ra, lds, 0);                                               // A(0)
+    stage_a(ra, lds + ABUF, ROWB);                                     // A(1)     (nk >= 4: always this tile's)
+    int sa = 0, sb = 0;                                                // slots of the current chunk
+    bool first_tile = true;
     for (;;) {
         const long long next_row = row + TM;
         const int next_rows = next_row < row_end ? (int)min((long long)TM, row_end - next_row) : 0;
         const bool has_next = next_rows > 0;
         const __amdgpu_buffer_rsrc_t ra_next = res_a(next_row, next_rows);      // (empty past the end: no traffic)
-        // 32-row sub-tiles of this wave that exist in the tile (4 in a whole tile; the last tile of a range may be short)
-        const int lm = min(4, max(0, (rows - wr * 128 + 31) >> 5));
+        const __amdgpu_buffer_rsrc_t rb_next = has_next ? rb : r_none;
         f32x16 acc[4][2];
-        // ONE instruction stream for whole and short tiles: every MFMA sits behind a wave-uniform test of its sub-tile
-        // (scalar compare + branch that falls through in a whole tile).  A second, unconditional copy of the loop for
-        // whole tiles made the compiler keep the accumulators in scratch memory (964-1048 spilled registers): not an option.
-        {
-            constexpr bool FULL = false;
-            for (int kc = 0; kc < nk; ++kc) {
-                // My share of this chunk has landed.  Vector-memory operations retire in issue order, so what may stay in
-                // flight is counted: behind chunk 0 of a `pre` tile sit chunk 1's 8 loads and the previous tile's 16 stores
-                // (with a residual its loads, already waited for, retired everything older than the stores); behind chunk 1
-                // only those stores -- the store drain of a tile (128 KB per CU at ~10 B/clk) overlaps the next tile's first
-                // two chunks instead of stalling its first wait.
-                if (pre && kc == 0) {
-                    if constexpr (HAS_RES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                } else if (pre && kc == 1) {
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();                               // ... everyone's; and the other buffer is free
-                const char *rd = lds + buf * BUFB;
-                char *wrb = lds + (buf ^ 1) * BUFB;
-                const bool do_dma = !(pre && kc == 0);                      // (chunk 1 of a `pre` tile is already in flight)
-                const bool more = kc + 1 < nk;
-                const __amdgpu_buffer_rsrc_t ra_nx = more ? ra : ra_next;
-                const __amdgpu_buffer_rsrc_t rb_nx = (more || has_next) ? rb : rsrc_at(A.wgt, 0, 0);
-                const int soff = more ? (kc + 1) * ROWB : 0;
-                // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the next chunk's 8 loads ride behind MFMAs 0 .. 7
-                f32x4 fa[2][4], fb[2][2];
-                auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) __attribute__((always_inline)) {
-                    const int slot16 = ((ks * 2 + h) ^ swz) * 16;
+        for (int kc = 0; kc < nk; ++kc) {
+            // what must have landed: A(c) and B(c).  In flight behind them, oldest first --
+            //   ordinary chunk:                  A(c+1)                                   -> 4 may stay
+            //   chunk 0 of a later tile:         A(c+1), B(c+1) [sent before the stores], the 16 stores  -> 24
+            //   chunk 1 of a later tile:         the 16 stores, A(c+1)  [chunk 0 sent A only]            -> 20
+            //   chunk 2 of a later tile needs B(c), which is YOUNGER than the stores: the store drain of a tile overlaps
+            //   the next tile's first two chunks and no more.
+            // (with a residual the epilogue's own waits have retired everything older than its stores: the counts hold)
+            if (!first_tile && kc == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (!first_tile && kc == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // ... everyone's; and chunk c - 1's slots are free
+            const char *rd_a = lds + sa * ABUF + a_off;
+            const char *rd_b = lds_b + sb * BBUF + b_off;
+            const int sa2 = sa == 0 ? 2 : sa - 1;                       // (c + 2) % 3 == (c - 1) % 3
+            char *wr_a = lds + sa2 * ABUF;
+            char *wr_b = lds_b + (sb ^ 1) * BBUF;
+            // sources of B(c+1) and A(c+2): this tile, or the head of the next one (empty extents past the block's end)
+            const bool b_here = kc + 1 < nk, a_here = kc + 2 < nk;
+            const __amdgpu_buffer_rsrc_t rb_nx = b_here ? rb : rb_next;
+            const __amdgpu_buffer_rsrc_t ra_nx = a_here ? ra : ra_next;
+            const int soff_b = b_here ? (kc + 1) * ROWB : 0;
+            const int soff_a = a_here ? (kc + 2) * ROWB : (kc + 2 - nk) * ROWB;
+            const bool send_b = first_tile || kc > 0;                   // (B of a later tile's chunk 1 went out before the stores)
+            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the 8 requests ride behind MFMAs 0 .. 7
+            f32x4 fa[2][4], fb[2][2];
+            auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) {
+                const int slot16 = ((ks * 2 + h) ^ swz) * 16;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd + a_off + m * 32 * ROWB + slot16);
+                for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd_a + m * 32 * ROWB + slot16);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4 *>(rd + b_off + n * 32 * ROWB + slot16);
-                };
-                read_frags(0, fa[0], fb[0]);
-                if (kc == 0) {                                             // a tile's chains start from 0 (once per tile)
+                for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4 *>(rd_b + n * 32 * ROWB + slot16);
+            };
+            read_frags(0, fa[0], fb[0]);
+            if (kc == 0) {                                             // a tile's chains start from 0 (once per tile)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-                }
-                static_for<0, 32>([&](auto ic) {
-                    constexpr int idx = decltype(ic)::value;               // ks * 8 + mi * 2 + ni
-                    constexpr int ks = idx >> 3, mi = (idx >> 1) & 3, ni = idx & 1;
-                    if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-                    if (FULL || mi < lm) {
-                        const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
-                    }
-                    if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
-                        constexpr int p = idx;                              // piece 0..7
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (do_dma) {
-                            if constexpr (p < 4) lds_dma16(ra_nx, wrb + (64 * p + 8 * wave) * ROWB, a_voff[p], soff);
-                            else lds_dma16(rb_nx, wrb + (TM + 64 * (p - 4) + 8 * wave) * ROWB, b_voff[p - 4], soff);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
-                buf ^= 1;
+                        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
             }
+            static_for<0, 32>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value;               // ks * 8 + mi * 2 + ni
+                constexpr int ks = idx >> 3, mi = (idx >> 1) & 3, ni = idx & 1;
+                if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+                if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
+                    constexpr int p = idx;                              // piece 0..7: B first (it is needed first)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (p < 4) {
+                        if (send_b) lds_dma16(rb_nx, wr_b + (64 * p + 8 * wave) * ROWB, b_voff[p], soff_b);
+                    } else {
+                        lds_dma16(ra_nx, wr_a + (64 * (p - 4) + 8 * wave) * ROWB, a_voff[p - 4], soff_a);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            sa = sa == 2 ? 0 : sa + 1;
+            sb ^= 1;
         }
-        // chunk 1 of the NEXT tile goes out before this tile's stores (its buffer, the last chunk's, is free once every
-        // wave has read its fragments): see the counted waits above
-        pre = has_next && nk >= 2;
-        if (pre) {
-            __builtin_amdgcn_s_barrier();
-            stage(ra_next, rb, lds + (buf ^ 1) * BUFB, ROWB);
-        }
+        // ---- between tiles.  Every wave has read the last chunk's slots (A slot `sl`, B slot sb ^ 1 -- `sa` / `sb` already
+        // name the next chunk's): B of the next tile's chunk 1 goes into that B slot NOW, ahead of the stores, and the A slot
+        // serves as the waves' transposition scratch until the next chunk's barrier (its next request comes after it).
+        const int sl = sa == 0 ? 2 : sa - 1;
+        __builtin_amdgcn_s_barrier();
+        stage_b(rb_next, lds_b + (sb ^ 1) * BBUF, ROWB);
+        char *scratch = lds + sl * ABUF + wave * SCRB;
 
-        // ---- epilogue of this tile (the next tile's first chunk is already on its way).  Four groups (mi) of four
-        // 16-row x 32-column pieces; the residual of group g + 1 is fetched (inline asm, counted waits) before group g's
-        // stores are issued, so no load ever waits for a store.  Rows past the tile's own are neither read nor stored
-        // (resource extents); a short tile -- always the last of its range -- skips the groups that do not exist.
+        // ---- epilogue of this tile.  Four groups (mi) of four 16-row x 32-column pieces; the residual of group g + 1 is
+        // fetched (inline asm, counted waits) before group g's stores are issued, so no load ever waits for a store.  Rows
+        // past the tile's own are neither read nor stored (resource extents).
         const long long tile_off = (row * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
         const int tile_bytes = rows * A.out_cs * 2 - (A.out_coff + nt * TN) * 2;
         const __amdgpu_buffer_rsrc_t ro = rsrc_span(A.out, tile_off, tile_bytes);
@@ -277,12 +282,19 @@ conv1x1_h256_kernel(const H256Args A) {
             return ((wr * 128 + mi * 32 + hs * 16 + t_row) * A.out_cs + wc * 64 + ni * 32 + t_col) * 2;
         };
         f32x4 rq[2][4];
-        auto load_group = [&](int mi, f32x4 (&q)[4]) __attribute__((always_inline)) {
+        auto load_group = [&](int mi, f32x4 (&q)[4]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = buf_load16_asm(rr, voff_of(mi, k >> 1, k & 1));
         };
-        auto store_group = [&](auto mc, f32x4 (&q)[4]) __attribute__((always_inline)) {
+        if constexpr (HAS_RES) load_group(0, rq[0]);
+        static_for<0, 4>([&](auto mc) {
             constexpr int mi = decltype(mc)::value;
+            if constexpr (HAS_RES) {
+                if constexpr (mi < 3) load_group(mi + 1, rq[(mi + 1) & 1]);
+                // younger than this group's loads: the next group's 4 loads and the previous group's 4 stores
+                constexpr int younger = (mi < 3 ? 4 : 0) + (mi > 0 ? 4 : 0);
+                wait_loaded4<younger>(rq[mi & 1][0], rq[mi & 1][1], rq[mi & 1][2], rq[mi & 1][3]);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ni = k >> 1, hs = k & 1;
@@ -294,7 +306,7 @@ conv1x1_h256_kernel(const H256Args A) {
                 }
                 f32x4 v0 = sr[0], v1 = sr[1];
                 if constexpr (HAS_RES) {
-                    const f16x8 rh = __builtin_bit_cast(f16x8, q[k]);
+                    const f16x8 rh = __builtin_bit_cast(f16x8, rq[mi & 1][k]);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { v0[c] += (float)rh[c]; v1[c] += (float)rh[4 + c]; }
                 }
@@ -311,36 +323,12 @@ conv1x1_h256_kernel(const H256Args A) {
                                  (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, voff_of(mi, ni, hs), 0, 0);
             }
-        };
-        if (rows == TM) {
-            if constexpr (HAS_RES) load_group(0, rq[0]);
-            static_for<0, 4>([&](auto mc) {
-                constexpr int mi = decltype(mc)::value;
-                if constexpr (HAS_RES) {
-                    if constexpr (mi < 3) load_group(mi + 1, rq[(mi + 1) & 1]);
-                    // younger than this group's loads: the next group's 4 loads and the previous group's 4 stores
-                    constexpr int younger = (mi < 3 ? 4 : 0) + (mi > 0 ? 4 : 0);
-                    wait_loaded4<younger>(rq[mi & 1][0], rq[mi & 1][1], rq[mi & 1][2], rq[mi & 1][3]);
-                }
-                store_group(mc, rq[mi & 1]);
-            });
-        } else {
-            // the short last tile: nothing follows it, so its groups need no pipelining -- load, wait for everything, store
-            static_for<0, 4>([&](auto mc) {
-                constexpr int mi = decltype(mc)::value;
-                if (mi < lm) {
-                    if constexpr (HAS_RES) {
-                        load_group(mi, rq[0]);
-                        wait_loaded4<0>(rq[0][0], rq[0][1], rq[0][2], rq[0][3]);
-                    }
-                    store_group(mc, rq[0]);
-                }
-            });
-        }
+        });
         if (!has_next) break;
         row = next_row;
         rows = next_rows;
         ra = ra_next;
+        first_tile = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -57,34 +57,11 @@ __device__ __forceinline__ void stage_to_lds(float *dst, const typename Stage16<
 constexpr int PS = 80;   // LDS floats per input pixel (64 channels + pad, = 16 mod 64)
 constexpr int CS = 64;   // channels per block
 
-// Block -> (tile x, tile y, 64-channel slab, image).  One-dimensional grid, XCD aware: blocks with equal id mod 8 share an
-// XCD and its L2 (MI355X_MICROARCH.md, workgroup dispatch), and each XCD walks ONE contiguous run of the work list
-// (image, tile row) > slab > tile x.  The ~256 blocks an XCD has in flight are then a few neighbouring tile rows of one
-// image, all slabs: the halo pixels two neighbouring tiles share (36 % of a 10 x 10 input patch) are fetched into that one L2
-// once instead of crossing the fabric once per XCD -- with the (x, slab, image) grid of rounds 1-3 neighbouring tiles sat
-// on eight different XCDs.  The split of the list over the 8 residues is the bijective one (sizes differ by at most 1).
-struct GGrid { int tiles_x, tiles_y, slabs, nblk; };
-struct GBlock { int tx, ty, cs0, b; };
-__device__ __forceinline__ GBlock gconv_block(const GGrid g) {
-    const int bid = (int)blockIdx.x;
-    const int x = bid & 7, w = bid >> 3;
-    const int q = g.nblk >> 3, r = g.nblk & 7;
-    const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
-    GBlock o;
-    o.tx = L % g.tiles_x;
-    const int t1 = L / g.tiles_x;
-    o.cs0 = (t1 % g.slabs) * CS;
-    const int row = t1 / g.slabs;
-    o.b = row / g.tiles_y;
-    o.ty = row - o.b * g.tiles_y;
-    return o;
-}
-
 template <int STRIDE, int TH, int TW, int CPG, class TIO>
 __global__ void __launch_bounds__(256)
 gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
                    TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
-                   const GGrid grid) {
+                   int tiles_x) {
     constexpr int c = CPG;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
@@ -99,8 +76,9 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
     static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
     extern __shared__ __align__(16) float tile[];   // [NPIX][PS]
 
-    const GBlock gb = gconv_block(grid);
-    const int tx = gb.tx, ty = gb.ty, cs0 = gb.cs0, b = gb.b;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
@@ -198,7 +176,7 @@ template <int STRIDE, int TH, int TW, int CPG>
 __global__ void __launch_bounds__(256)
 gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
                     _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
-                    const GGrid grid) {
+                    int tiles_x) {
     constexpr int c = CPG;
     constexpr int PSH = PixH<STRIDE>::value;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
@@ -213,8 +191,9 @@ gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ w
     static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
     extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PSH]
 
-    const GBlock gb = gconv_block(grid);
-    const int tx = gb.tx, ty = gb.ty, cs0 = gb.cs0, b = gb.b;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
@@ -306,7 +285,7 @@ constexpr int PS16 = 68;   // LDS floats per pixel: 16 consecutive pixels x 16 B
 template <int STRIDE, int TH, int TW, class TIO>
 __global__ void __launch_bounds__(256)
 gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-               TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, const GGrid grid) {
+               TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
@@ -318,8 +297,9 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
     static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
     extern __shared__ __align__(16) float tile[];   // [NPIX][PS16]
 
-    const GBlock gb = gconv_block(grid);
-    const int tx = gb.tx, ty = gb.ty, cs0 = gb.cs0, b = gb.b;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
@@ -400,7 +380,7 @@ constexpr int PS16H = 72;  // LDS halves per pixel (144 B)
 template <int STRIDE, int TH, int TW>
 __global__ void __launch_bounds__(256)
 gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, const GGrid grid) {
+                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
@@ -411,8 +391,9 @@ gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
     static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
     extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PS16H]
 
-    const GBlock gb = gconv_block(grid);
-    const int tx = gb.tx, ty = gb.ty, cs0 = gb.cs0, b = gb.b;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int cs0 = blockIdx.y * CS;
+    const int b = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
@@ -507,11 +488,8 @@ int launch16(const TIO *in, const float *wgt, const float *bias, TIO *out, int B
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    const long long nblk = (long long)tiles_x * tiles_y * (C / CS) * B;
-    ML_REQUIRE(nblk < (1ll << 31), "gconv3x3: grid too large");
-    const GGrid grid = {tiles_x, tiles_y, C / CS, (int)nblk};
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho,
-                       Wo, pad_t, pad_l, act, grid);
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho,
+                       Wo, pad_t, pad_l, act, tiles_x);
     ML_CHECK_LAUNCH("gconv3x3");
     return ML_OK;
 }
@@ -526,11 +504,8 @@ int launch(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, 
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    const long long nblk = (long long)tiles_x * tiles_y * (C / CS) * B;
-    ML_REQUIRE(nblk < (1ll << 31), "gconv3x3: grid too large");
-    const GGrid grid = {tiles_x, tiles_y, C / CS, (int)nblk};
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C,
-                       Ho, Wo, pad_t, pad_l, act, grid);
+    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C,
+                       Ho, Wo, pad_t, pad_l, act, tiles_x);
     ML_CHECK_LAUNCH("gconv3x3");
     return ML_OK;
 }

@@ -64,6 +64,14 @@ def main():
         if 4 in outs and 5 in outs:
             d = (outs[4].float() - outs[5].float()).abs().max().item()
             line += f" | max diff {d:.3g}  nan {bool(torch.isnan(outs[5]).any())}"
+            # race screen: a staged buffer read before its request landed shows as RARE wrong tiles -- repeat the launch
+            # into fresh buffers (cold / warm caches, other data in LDS from the previous launch) and compare every time
+            dc5 = ops.DeviceConv(packing.pack_dense(w, b, tile=5), "cuda")
+            bad = 0
+            for i in range(30):
+                o = ops.conv2d(x, dc5, padding="same", act=_lib.ACT_RELU, residual=r)
+                bad += int(not torch.equal(o, outs[4]))
+            line += f" | repeat mismatches {bad}/30"
         print(line, flush=True)
 
 
