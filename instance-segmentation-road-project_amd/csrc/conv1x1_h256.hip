@@ -37,6 +37,17 @@
 
 namespace {
 
+// experiment knobs (scripts/experiments): spacing of the LDS-direct requests in the MFMA stream, and ablations that send the
+// A / B requests through an empty extent (same instructions, no traffic; results are then wrong)
+#ifndef H256_DMA_STRIDE
+#define H256_DMA_STRIDE 1
+#endif
+#ifndef H256_ABL_A
+#define H256_ABL_A 0
+#endif
+#ifndef H256_ABL_B
+#define H256_ABL_B 0
+#endif
 constexpr int TM = 256, TN = 256;                  // block tile
 constexpr int ROWB = 128;                          // bytes of K per staged row and chunk (64 halves)
 constexpr int ABUF = TM * ROWB, BBUF = TN * ROWB;  // one chunk of the A tile / of the B tile: 32 KB each
@@ -185,46 +196,123 @@ conv1x1_h256_kernel(const H256Args A) {
     // buffers (round 3) at most 64 KB per CU were in flight, and 64 KB per ~2.2 us is exactly the ~29 GB/s per CU that
     // kernel stood at; here it is 64 KB of A + 32 KB of B.  Vector-memory operations retire in issue order, so every wait is
     // a COUNT of what may stay in flight behind the requests that are needed.
+    struct Chunk {
+        const char *rd_a, *rd_b;                 // this chunk's A / B slot
+        char *wr_a, *wr_b;                       // where A(c + 2) / B(c + 1) land
+        __amdgpu_buffer_rsrc_t ra_nx, rb_nx;
+        int soff_a, soff_b;
+        bool send_b;
+    };
     __amdgpu_buffer_rsrc_t ra = res_a(row, rows);
     stage_b(rb, lds_b, 0);                                             // B(0)
     stage_a(ra, lds, 0);                                               // A(0)
     stage_a(ra, lds + ABUF, ROWB);                                     // A(1)     (nk >= 4: always this tile's)
     int sa = 0, sb = 0;                                                // slots of the current chunk
     bool first_tile = true;
+    __amdgpu_buffer_rsrc_t ra_next = r_none, rb_next = r_none;         // the tile after the current one (empty: none)
+
+    auto begin_chunk = [&](int kc) __attribute__((always_inline)) {
+        // what must have landed: A(c) and B(c).  In flight behind them, oldest first --
+        //   ordinary chunk:                  A(c+1)                                   -> 4 may stay
+        //   chunk 0 of a later tile:         A(c+1), B(c+1) [sent before the stores], the 16 stores  -> 24
+        //   chunk 1 of a later tile:         the 16 stores, A(c+1)  [chunk 0 sent A only]            -> 20
+        //   chunk 2 of a later tile needs B(c), which is YOUNGER than the stores: the store drain of a tile overlaps
+        //   the next tile's first two chunks and no more.
+        // (with a residual the epilogue's own waits have retired everything older than its stores: the counts hold)
+        if (!first_tile && kc == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (!first_tile && kc == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // ... everyone's; and chunk c - 1's slots are free
+        Chunk C;
+        C.rd_a = lds + sa * ABUF;
+        C.rd_b = lds_b + sb * BBUF;
+        const int sa2 = sa == 0 ? 2 : sa - 1;                       // (c + 2) % 3 == (c - 1) % 3
+        C.wr_a = lds + sa2 * ABUF;
+        C.wr_b = lds_b + (sb ^ 1) * BBUF;
+        // sources of B(c+1) and A(c+2): this tile, or the head of the next one (empty extents past the block's end)
+        const bool b_here = kc + 1 < nk, a_here = kc + 2 < nk;
+        C.rb_nx = b_here ? rb : rb_next;
+        C.ra_nx = a_here ? ra : ra_next;
+        C.soff_b = b_here ? (kc + 1) * ROWB : 0;
+        C.soff_a = a_here ? (kc + 2) * ROWB : (kc + 2 - nk) * ROWB;
+        C.send_b = first_tile || kc > 0;                            // (B of a later tile's chunk 1 went out before the stores)
+        return C;
+    };
+    auto send_piece = [&](const Chunk &C, auto pc) __attribute__((always_inline)) {     // piece 0..7: B first (needed first)
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < 4) {
+            if (C.send_b) lds_dma16(H256_ABL_B ? r_none : C.rb_nx, C.wr_b + (64 * p + 8 * wave) * ROWB, b_voff[p], C.soff_b);
+        } else {
+            lds_dma16(H256_ABL_A ? r_none : C.ra_nx, C.wr_a + (64 * (p - 4) + 8 * wave) * ROWB, a_voff[p - 4], C.soff_a);
+        }
+    };
+    auto end_chunk = [&]() __attribute__((always_inline)) {
+        sa = sa == 2 ? 0 : sa + 1;
+        sb ^= 1;
+    };
+    // between tiles: every wave has read the last chunk's slots (A slot `sl`, B slot sb ^ 1 -- `sa` / `sb` already name the
+    // next chunk's).  B of the next tile's chunk 1 goes into that B slot NOW, ahead of the stores, and the A slot serves as
+    // the waves' transposition scratch until the next chunk's barrier (its next request comes after that barrier).
+    auto between_tiles = [&]() __attribute__((always_inline)) {
+        const int sl = sa == 0 ? 2 : sa - 1;
+        __builtin_amdgcn_s_barrier();
+        stage_b(rb_next, lds_b + (sb ^ 1) * BBUF, ROWB);
+        return lds + sl * ABUF + wave * SCRB;
+    };
+    // one 16-row x 32-column piece of the epilogue: 8 accumulator registers of a 32 x 32 tile -> the wave's scratch ->
+    // rows of 8 consecutive columns per lane, + residual (8 halves) + bias, clamp, one rounding, one 16-byte store
+    auto finish_piece = [&](char *scratch, const f32x16 &acc, int hs, const f32x4 &res8, const f32x4 &b0, const f32x4 &b1,
+                            __amdgpu_buffer_rsrc_t ro, int voff) __attribute__((always_inline)) {
+        float *sw = reinterpret_cast<float *>(scratch + scr_w);
+        const f32x4 *sr = reinterpret_cast<const f32x4 *>(scratch + scr_r);
+        // C/D layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)) -> scratch[row][col]
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = hs * 8 + e8;
+            sw[((e & 3) + 8 * ((e >> 2) & 1)) * SCR_LD] = acc[e];
+        }
+        f32x4 v0 = sr[0], v1 = sr[1];
+        if constexpr (HAS_RES) {
+            const f16x8 rh = __builtin_bit_cast(f16x8, res8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v0[c] += (float)rh[c]; v1[c] += (float)rh[4 + c]; }
+        }
+        v0 += b0;
+        v1 += b1;
+        if (A.clamp) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v0[c] = __builtin_amdgcn_fmed3f(v0[c], A.lo, A.hi);
+                v1[c] = __builtin_amdgcn_fmed3f(v1[c], A.lo, A.hi);
+            }
+        }
+        const f16x8 o = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                         (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, voff, 0, 0);
+    };
+    auto out_rsrc = [&](long long r0, int nrows, __amdgpu_buffer_rsrc_t &ro, i32x4 &rr) __attribute__((always_inline)) {
+        const long long tile_off = (r0 * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
+        const int tile_bytes = nrows * A.out_cs * 2 - (A.out_coff + nt * TN) * 2;
+        ro = rsrc_span(A.out, tile_off, tile_bytes);
+        const unsigned long long rbase = (unsigned long long)((const char *)A.res + (HAS_RES ? tile_off : 0));
+        rr = i32x4{(int)(unsigned)rbase, (int)((unsigned)(rbase >> 32) & 0xffffu), HAS_RES ? tile_bytes : 0, 0x00020000};
+    };
+
+    // ---- whole tiles (and short last tiles of more than 128 rows, which run the same stream on zero-filled rows)
+    int tail_q = 0;                                       // 32-row groups of a short last tile that takes the light path below
     for (;;) {
         const long long next_row = row + TM;
         const int next_rows = next_row < row_end ? (int)min((long long)TM, row_end - next_row) : 0;
         const bool has_next = next_rows > 0;
-        const __amdgpu_buffer_rsrc_t ra_next = res_a(next_row, next_rows);      // (empty past the end: no traffic)
-        const __amdgpu_buffer_rsrc_t rb_next = has_next ? rb : r_none;
+        ra_next = res_a(next_row, next_rows);                          // (empty past the end: no traffic)
+        rb_next = has_next ? rb : r_none;
         f32x16 acc[4][2];
         for (int kc = 0; kc < nk; ++kc) {
-            // what must have landed: A(c) and B(c).  In flight behind them, oldest first --
-            //   ordinary chunk:                  A(c+1)                                   -> 4 may stay
-            //   chunk 0 of a later tile:         A(c+1), B(c+1) [sent before the stores], the 16 stores  -> 24
-            //   chunk 1 of a later tile:         the 16 stores, A(c+1)  [chunk 0 sent A only]            -> 20
-            //   chunk 2 of a later tile needs B(c), which is YOUNGER than the stores: the store drain of a tile overlaps
-            //   the next tile's first two chunks and no more.
-            // (with a residual the epilogue's own waits have retired everything older than its stores: the counts hold)
-            if (!first_tile && kc == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (!first_tile && kc == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                               // ... everyone's; and chunk c - 1's slots are free
-            const char *rd_a = lds + sa * ABUF + a_off;
-            const char *rd_b = lds_b + sb * BBUF + b_off;
-            const int sa2 = sa == 0 ? 2 : sa - 1;                       // (c + 2) % 3 == (c - 1) % 3
-            char *wr_a = lds + sa2 * ABUF;
-            char *wr_b = lds_b + (sb ^ 1) * BBUF;
-            // sources of B(c+1) and A(c+2): this tile, or the head of the next one (empty extents past the block's end)
-            const bool b_here = kc + 1 < nk, a_here = kc + 2 < nk;
-            const __amdgpu_buffer_rsrc_t rb_nx = b_here ? rb : rb_next;
-            const __amdgpu_buffer_rsrc_t ra_nx = a_here ? ra : ra_next;
-            const int soff_b = b_here ? (kc + 1) * ROWB : 0;
-            const int soff_a = a_here ? (kc + 2) * ROWB : (kc + 2 - nk) * ROWB;
-            const bool send_b = first_tile || kc > 0;                   // (B of a later tile's chunk 1 went out before the stores)
-            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the 8 requests ride behind MFMAs 0 .. 7
+            const Chunk C = begin_chunk(kc);
+            const char *rd_a = C.rd_a + a_off, *rd_b = C.rd_b + b_off;
+            // 4 k-steps of 16: 6 fragment reads + 8 MFMAs each; the 8 requests ride behind the first MFMAs
             f32x4 fa[2][4], fb[2][2];
-            auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) {
+            auto read_frags = [&](int ks, f32x4 (&a)[4], f32x4 (&b)[2]) __attribute__((always_inline)) {
                 const int slot16 = ((ks * 2 + h) ^ swz) * 16;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd_a + m * 32 * ROWB + slot16);
@@ -246,43 +334,27 @@ conv1x1_h256_kernel(const H256Args A) {
                 if constexpr ((idx & 7) == 2 && ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
                 const f16x8 a = __builtin_bit_cast(f16x8, fa[ks & 1][mi]), b = __builtin_bit_cast(f16x8, fb[ks & 1][ni]);
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
-                if constexpr (idx < 8) {                                // early: the rest of the chunk is their flight time
-                    constexpr int p = idx;                              // piece 0..7: B first (it is needed first)
+                if constexpr (idx % H256_DMA_STRIDE == 0 && idx / H256_DMA_STRIDE < 8) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (p < 4) {
-                        if (send_b) lds_dma16(rb_nx, wr_b + (64 * p + 8 * wave) * ROWB, b_voff[p], soff_b);
-                    } else {
-                        lds_dma16(ra_nx, wr_a + (64 * (p - 4) + 8 * wave) * ROWB, a_voff[p - 4], soff_a);
-                    }
+                    send_piece(C, std::integral_constant<int, idx / H256_DMA_STRIDE>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            sa = sa == 2 ? 0 : sa + 1;
-            sb ^= 1;
+            end_chunk();
         }
-        // ---- between tiles.  Every wave has read the last chunk's slots (A slot `sl`, B slot sb ^ 1 -- `sa` / `sb` already
-        // name the next chunk's): B of the next tile's chunk 1 goes into that B slot NOW, ahead of the stores, and the A slot
-        // serves as the waves' transposition scratch until the next chunk's barrier (its next request comes after it).
-        const int sl = sa == 0 ? 2 : sa - 1;
-        __builtin_amdgcn_s_barrier();
-        stage_b(rb_next, lds_b + (sb ^ 1) * BBUF, ROWB);
-        char *scratch = lds + sl * ABUF + wave * SCRB;
+        char *scratch = between_tiles();
 
         // ---- epilogue of this tile.  Four groups (mi) of four 16-row x 32-column pieces; the residual of group g + 1 is
         // fetched (inline asm, counted waits) before group g's stores are issued, so no load ever waits for a store.  Rows
         // past the tile's own are neither read nor stored (resource extents).
-        const long long tile_off = (row * A.out_cs + A.out_coff + (long long)nt * TN) * 2;
-        const int tile_bytes = rows * A.out_cs * 2 - (A.out_coff + nt * TN) * 2;
-        const __amdgpu_buffer_rsrc_t ro = rsrc_span(A.out, tile_off, tile_bytes);
-        const unsigned long long rbase = (unsigned long long)((const char *)A.res + (HAS_RES ? tile_off : 0));
-        const i32x4 rr = {(int)(unsigned)rbase, (int)((unsigned)(rbase >> 32) & 0xffffu), HAS_RES ? tile_bytes : 0, 0x00020000};
-        float *sw = reinterpret_cast<float *>(scratch + scr_w);
-        const f32x4 *sr = reinterpret_cast<const f32x4 *>(scratch + scr_r);
+        __amdgpu_buffer_rsrc_t ro;
+        i32x4 rr;
+        out_rsrc(row, rows, ro, rr);
         auto voff_of = [&](int mi, int ni, int hs) {
             return ((wr * 128 + mi * 32 + hs * 16 + t_row) * A.out_cs + wc * 64 + ni * 32 + t_col) * 2;
         };
         f32x4 rq[2][4];
-        auto load_group = [&](int mi, f32x4 (&q)[4]) {
+        auto load_group = [&](int mi, f32x4 (&q)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = buf_load16_asm(rr, voff_of(mi, k >> 1, k & 1));
         };
@@ -298,30 +370,7 @@ conv1x1_h256_kernel(const H256Args A) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ni = k >> 1, hs = k & 1;
-                // C/D layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)) -> scratch[row][col]
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const int e = hs * 8 + e8;
-                    sw[((e & 3) + 8 * ((e >> 2) & 1)) * SCR_LD] = acc[mi][ni][e];
-                }
-                f32x4 v0 = sr[0], v1 = sr[1];
-                if constexpr (HAS_RES) {
-                    const f16x8 rh = __builtin_bit_cast(f16x8, rq[mi & 1][k]);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { v0[c] += (float)rh[c]; v1[c] += (float)rh[4 + c]; }
-                }
-                v0 += bias[ni][0];
-                v1 += bias[ni][1];
-                if (A.clamp) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        v0[c] = __builtin_amdgcn_fmed3f(v0[c], A.lo, A.hi);
-                        v1[c] = __builtin_amdgcn_fmed3f(v1[c], A.lo, A.hi);
-                    }
-                }
-                const f16x8 o = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
-                                 (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, voff_of(mi, ni, hs), 0, 0);
+                finish_piece(scratch, acc[mi][ni], hs, rq[mi & 1][k], bias[ni][0], bias[ni][1], ro, voff_of(mi, ni, hs));
             }
         });
         if (!has_next) break;
@@ -329,6 +378,79 @@ conv1x1_h256_kernel(const H256Args A) {
         rows = next_rows;
         ra = ra_next;
         first_tile = false;
+        if (rows <= 128) {                                // a short last tile: the light path
+            tail_q = (rows + 31) >> 5;
+            break;
+        }
+    }
+
+    // ---- the short last tile of the range (<= 128 rows = Q <= 4 groups of 32): the SAME chunk stream -- its requests are
+    // already in flight -- but another split of the work: wave w takes columns 32 w .. 32 w + 31 of the N tile and all Q row
+    // groups, Q MFMAs per 16-deep step instead of 8 of which 8 - 2Q.. would multiply zero rows.  A range of 3.125 tiles
+    // then costs 3 tiles and a fraction instead of 4.  Own accumulators, own (unpipelined) epilogue; nothing follows it.
+    auto tail = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(qc)::value;
+        ra_next = r_none;
+        rb_next = r_none;
+        f32x16 acc_t[Q];
+        const int ta_off = r * ROWB, tb_off = (wave * 32 + r) * ROWB;
+        for (int kc = 0; kc < nk; ++kc) {
+            const Chunk C = begin_chunk(kc);
+            const char *rd_a = C.rd_a + ta_off, *rd_b = C.rd_b + tb_off;
+            f32x4 fa[2][Q], fb[2];
+            auto read_frags = [&](int ks, f32x4 (&a)[Q], f32x4 &b) __attribute__((always_inline)) {
+                const int slot16 = ((ks * 2 + h) ^ swz) * 16;
+#pragma unroll
+                for (int m = 0; m < Q; ++m) a[m] = *reinterpret_cast<const f32x4 *>(rd_a + m * 32 * ROWB + slot16);
+                b = *reinterpret_cast<const f32x4 *>(rd_b + slot16);
+            };
+            read_frags(0, fa[0], fb[0]);
+            if (kc == 0) {
+#pragma unroll
+                for (int m = 0; m < Q; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc_t[m][e] = 0.f;
+            }
+            static_for<0, 8>([&](auto pc) { send_piece(C, pc); });
+            static_for<0, 4>([&](auto kc4) {
+                constexpr int ks = decltype(kc4)::value;
+                if constexpr (ks < 3) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+                for (int m = 0; m < Q; ++m)
+                    acc_t[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ks & 1][m]),
+                                                                      __builtin_bit_cast(f16x8, fb[ks & 1]), acc_t[m], 0, 0, 0);
+            });
+            end_chunk();
+        }
+        char *scratch = between_tiles();
+        __amdgpu_buffer_rsrc_t ro;
+        i32x4 rr;
+        out_rsrc(row, rows, ro, rr);
+        f32x4 bt[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = nt * TN + wave * 32 + t_col + 4 * k;
+            bt[k] = A.bias ? *reinterpret_cast<const f32x4 *>(A.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int m = 0; m < Q; ++m)
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                const int voff = ((m * 32 + hs * 16 + t_row) * A.out_cs + wave * 32 + t_col) * 2;
+                f32x4 res8 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (HAS_RES) {
+                    res8 = buf_load16_asm(rr, voff);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(res8));
+                }
+                finish_piece(scratch, acc_t[m], hs, res8, bt[0], bt[1], ro, voff);
+            }
+    };
+    switch (tail_q) {
+        case 1: tail(std::integral_constant<int, 1>{}); break;
+        case 2: tail(std::integral_constant<int, 2>{}); break;
+        case 3: tail(std::integral_constant<int, 3>{}); break;
+        case 4: tail(std::integral_constant<int, 4>{}); break;
+        default: break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -441,15 +441,35 @@ def test_full_per_gpu_batch_of_the_headline_config():
             assert any("k7x7" in lb for lb in same) and any("HxW=256x256" in lb for lb in same)   # stem / stage 2: same sums
             mine = FX.image_of_batch(names, outs, lcounts, k)
             n1 = int(d1["counts"].cpu()[0])
-            np.testing.assert_array_equal(kept[k, :counts[k]], d1["kept"].cpu().numpy()[0, :n1])   # same rows, same order
+            floats = {"cls_pred", "loc_pred", "seg_pred"}
             for name, a, b in zip(names, mine, alone):
-                assert a.shape == b.shape, name
-                if name == "roi_boxes":
-                    np.testing.assert_array_equal(a[..., 4], b[..., 4])
-                    np.testing.assert_allclose(a[..., :4], b[..., :4], rtol=1e-5, atol=1e-4)
-                    np.testing.assert_allclose(a[..., 5], b[..., 5], rtol=0, atol=5e-5)
-                else:
-                    assert float(np.abs(a - b).max()) <= 5e-5, name
+                if name in floats:
+                    assert a.shape == b.shape and float(np.abs(a - b).max()) <= 5e-5, name
+            if k == 0:
+                # the fixture image (threshold in a score gap, no near-ties among the kept scores): the same rows in the same
+                # order whichever launch shapes computed the scores, and the same RoI outputs
+                np.testing.assert_array_equal(kept[k, :counts[k]], d1["kept"].cpu().numpy()[0, :n1])
+                for name, a, b in zip(names, mine, alone):
+                    assert a.shape == b.shape, name
+                    if name == "roi_boxes":
+                        np.testing.assert_array_equal(a[..., 4], b[..., 4])
+                        np.testing.assert_allclose(a[..., :4], b[..., :4], rtol=1e-5, atol=1e-4)
+                        np.testing.assert_allclose(a[..., 5], b[..., 5], rtol=0, atol=5e-5)
+                    elif name == "roi_masks":
+                        assert float(np.abs(a - b).max()) <= 5e-5, name
+            else:
+                # any other image: min_confidence was not placed in ITS score gaps, so a score within rounding of the
+                # threshold (or of another candidate's) may legitimately come out differently in the two runs.  What must
+                # hold for both: the detection stage is exact on the predictions it was given -- the oracle's
+                # DetectionProposal (reference engine/layers/detection.py:482-567) on the GPU's own cls_pred / loc_pred
+                # returns the GPU's rows, in order.
+                det_cfg = cfg.detection
+                for preds, kk, nn in ((mine, kept[k], int(counts[k])), (alone, d1["kept"].cpu().numpy()[0], n1)):
+                    cp, lp = preds[names.index("cls_pred")], preds[names.index("loc_pred")]
+                    _, kept_self = O.detection_proposal(cp, FX.boxes_from(cfg, lp, size, size), fx["thr"],
+                                                        det_cfg.nms_iou_threshold, det_cfg.post_iou_threshold,
+                                                        det_cfg.nms_max_output_size)
+                    np.testing.assert_array_equal(kk[:nn], kept_self[:, 1:])
     finally:
         ops.LAUNCH_LOG = None
 
