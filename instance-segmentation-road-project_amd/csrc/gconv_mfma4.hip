@@ -54,6 +54,9 @@ __device__ __forceinline__ void stage_to_lds(float *dst, const typename Stage16<
     }
 }
 
+#ifndef GCONV_TH1_HALF
+#define GCONV_TH1_HALF 16          // (experiment knob: rows of a stride-1 tile on half tensors)
+#endif
 constexpr int PS = 80;   // LDS floats per input pixel (64 channels + pad, = 16 mod 64)
 constexpr int CS = 64;   // channels per block
 
@@ -528,14 +531,21 @@ static int gconv3x3_any(const TIO *in, const float *wgt, const float *bias, TIO 
     ML_REQUIRE((long long)B * H * W < (1ll << 31), "gconv3x3: too many pixels");
     hipStream_t s = (hipStream_t)stream;
 #define GC_ARGS in, wgt, bias, out, B, H, W, C, Ho, Wo, pad_t, pad_l, act, s
+    // Tile heights: half tensors take tiles twice as tall as fp32 ones.  A halo pixel of a 64-channel slab is ONE 128-byte
+    // line in half (two in fp32), so a half block of the fp32 tile shape moves half the bytes per request and per block
+    // prologue; 16 x 8 (stride 2: 8 x 8) tiles cut the halo share from 56 % to 41 % of a patch and measured 9-29 % faster
+    // on the 16 x 1280^2 ResNeXt-101 shapes (gpurun_out/r04g_gconv_*.txt), while fp32 tensors lose 2-14 % with them
+    // (22-46 KB of LDS per block: fewer blocks per CU to hide the load -> LDS -> compute chain of a block).
+    constexpr bool HALF = sizeof(TIO) == 2;
+    constexpr int TH1 = HALF ? GCONV_TH1_HALF : 8, TH2 = HALF ? 8 : 4;
     if (stride == 1) {
-        if (c == 4) return launch<1, 8, 8, 4, TIO>(GC_ARGS);
-        if (c == 8) return launch<1, 8, 8, 8, TIO>(GC_ARGS);
-        return launch16<1, 8, 8, TIO>(GC_ARGS);
+        if (c == 4) return launch<1, TH1, 8, 4, TIO>(GC_ARGS);
+        if (c == 8) return launch<1, TH1, 8, 8, TIO>(GC_ARGS);
+        return launch16<1, TH1, 8, TIO>(GC_ARGS);
     }
-    if (c == 4) return launch<2, 4, 8, 4, TIO>(GC_ARGS);
-    if (c == 8) return launch<2, 4, 8, 8, TIO>(GC_ARGS);
-    return launch16<2, 4, 8, TIO>(GC_ARGS);
+    if (c == 4) return launch<2, TH2, 8, 4, TIO>(GC_ARGS);
+    if (c == 8) return launch<2, TH2, 8, 8, TIO>(GC_ARGS);
+    return launch16<2, TH2, 8, TIO>(GC_ARGS);
 #undef GC_ARGS
 }
 

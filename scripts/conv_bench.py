@@ -91,12 +91,49 @@ def half_pipe(reps):
     ops.set_conv_math("f32")
 
 
+def half_heads(reps):
+    """the generic kernel on fp16 tensors: the head convs of the 16 x 1280^2 ResNeXt-101 workload (3x3, 128 / 256 channels).
+    Prints a checksum of the output (sum of the half bit patterns) so that two library builds can be compared for equality."""
+    rng = np.random.default_rng(0)
+    ops.set_conv_math("f16s")
+    shapes = [("P3 tower 3x3 128->128", 16, 160, 160, 128, 128, 3), ("P4 tower 3x3 128->128", 16, 80, 80, 128, 128, 3),
+              ("FPN P3 3x3 128->128", 16, 160, 160, 128, 128, 3), ("decoder 3x3 160->128", 16, 160, 160, 160, 128, 3),
+              ("mask 3x3 128->128 (1600 rois)", 1600, 14, 14, 128, 128, 3), ("lateral 1x1 2048->128", 16, 40, 40, 2048, 128, 1)]
+    for label, B, H, W, cin, cout, k in shapes:
+        x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float16)).cuda()
+        w = rng.normal(size=(k, k, cin, cout)).astype(np.float32) * 0.05
+        dc = ops.DeviceConv(packing.pack_dense(w, np.zeros(cout, np.float32)), "cuda")
+        out = torch.empty((B, H, W, cout), dtype=torch.float16, device="cuda")
+        for _ in range(3):
+            ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, out=out)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                ops.conv2d(x, dc, padding="same", act=_lib.ACT_RELU, out=out)
+            e.record()
+            torch.cuda.synchronize()
+            best = min(best, s.elapsed_time(e) / reps)
+        gf = 2.0 * out.numel() * k * k * cin / 1e9
+        chk = int(out.view(torch.int16).to(torch.int64).sum().item())
+        print(f"{label:32s} {1e3 * best:8.1f} us {gf / best:7.1f} TF/s   checksum {chk}", flush=True)
+    ops.set_conv_math("f32")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--half-heads", action="store_true")
+    ap.add_argument("--lib", default=None, help="an experiment build of the library (the product path has no override)")
     ap.add_argument("--ab-pipe", action="store_true")
     ap.add_argument("--half-pipe", action="store_true")
     args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+    if args.half_heads:
+        return half_heads(args.reps)
     if args.ab_pipe:
         return ab_pipe(args.reps)
     if args.half_pipe:
