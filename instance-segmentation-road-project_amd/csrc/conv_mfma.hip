@@ -204,14 +204,13 @@ __device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, cons
 // apply pass adds the pairs of a chunk's tiles in order instead of re-reading the tensor (csrc/groupnorm.hip).  A separate
 // instantiation: the kernel every other conv runs is untouched.
 template <int WAVES_M, int WAVES_N, int TM, int TN, int MATH, bool GNS = false, int NSTAGE = 2>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (GNS || MATH == ML_MATH_F32X3 || WAVES_M * WAVES_N == 8) ? 2 : 1)      // (second figure: waves per SIMD;
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (GNS || MATH == ML_MATH_F32X3) ? 2 : 1)      // (second figure: waves per SIMD;
 conv_mfma_kernel(const MultiArgs args) {                                          //  GNS: 262 registers otherwise)
     constexpr int NT = 64 * WAVES_M * WAVES_N;     // threads per block: 256 (4 waves), or 512 for the 256-row X3 tile
     constexpr int RPP = NT / 8;                    // rows one staging pass of the block covers (8 lanes x 16 B per row)
     static_assert(!GNS || (NT == 256 && WAVES_M * TM == 4) || (NT == 512 && WAVES_M * TM == 8),
                   "the GroupNorm partial sums: 4 pairs per 128-row tile, from 4 waves or from 8 waves on 256 rows");
-    static_assert(NSTAGE == 2 || (NSTAGE == 3 && (MATH == ML_MATH_F32X3 || MATH == ML_MATH_F16S)),
-                  "the 3-deep ring belongs to the 256-row tiles of the f16-pipe modes (short chunks: 16-24 MFMAs of 32 cycles)");
+    static_assert(NSTAGE == 2 || (NSTAGE == 3 && MATH == ML_MATH_F32X3), "the 3-deep ring is the X3 form");
     constexpr bool F16 = MATH == ML_MATH_F16;      // fp32 tensors, converted on the way into (padded, half) LDS rows
     constexpr bool HS = MATH == ML_MATH_F16S;      // half tensors, staged like fp32 ones
     constexpr bool X3 = MATH == ML_MATH_F32X3;     // fp32 tensors, staged like ML_MATH_F32; split products on the f16 MFMA
@@ -1297,20 +1296,6 @@ static int x3_adjust_tile(const ml_conv2d_desc *descs, int n, int t) {
     return short_k_res ? 2 : t;
 }
 
-// ML_MATH_F16S (half tensors: the heads of the fp16 path): 256 x 128 tiles on 8 waves with the 3-deep ring once they fill
-// the chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB, requests two chunks ahead.  Bit-identical
-// to the 128-row kernel (same k-ordered chains).
-static bool hs_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
-    if (t != 1 || descs[0].math != ML_MATH_F16S) return false;
-    long long big = 0;
-    for (int i = 0; i < n; ++i) {
-        if (descs[i].live) return false;                          // (the dead-tile test counts 128-row tiles)
-        const long long M = (long long)descs[i].B * descs[i].Ho * descs[i].Wo;
-        big += ((M + 255) / 256) * (descs[i].n_pad / 128);
-    }
-    return big >= ml_resident_blocks(1);
-}
-
 // ML_MATH_F32X3: 256 x 128 tiles (8 waves, one block per CU, 3-deep ring, software-pipelined steps) once they fill the
 // chip -- 48 KB staged per chunk for twice the MFMAs of a 128-row tile's 32 KB.  Results are bit-identical to the 128-row kernel's: the same k-ordered chains.
 static bool x3_uses_256_row_tiles(const ml_conv2d_desc *descs, int n, int t) {
@@ -1374,8 +1359,6 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     long long ref_tiles = -1;
     const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles));
     if (descs[0].math == ML_MATH_F16S) {
-        if (hs_uses_256_row_tiles(descs, n, t))
-            return launch_multi<8, 1, 1, 4, ML_MATH_F16S, false, 3>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         switch (t) {
             case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
             case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
@@ -1430,7 +1413,7 @@ extern "C" int ml_conv2d_launch_mtile(const ml_conv2d_desc *descs, int32_t n, in
     const int t0 = pick_tile(descs[0].cout, descs[0].tile);
     long long ref_tiles = -1;
     const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, has_workspace != 0, &ref_tiles));
-    return (x3_uses_256_row_tiles(descs, n, t) || hs_uses_256_row_tiles(descs, n, t)) ? 256 : 128;
+    return x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
 }
 
 // K slices per problem of the launch ml_conv2d_multi_f32 would make for these problems (1 = not split; the persistent
@@ -1443,7 +1426,7 @@ extern "C" int ml_conv2d_launch_splits(const ml_conv2d_desc *descs, int32_t n, i
     const int t0 = pick_tile(descs[0].cout, descs[0].tile);
     long long ref_tiles = -1;
     const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, workspace_bytes > 0, &ref_tiles));
-    const int BM = (x3_uses_256_row_tiles(descs, n, t) || hs_uses_256_row_tiles(descs, n, t)) ? 256 : 128;
+    const int BM = x3_uses_256_row_tiles(descs, n, t) ? 256 : 128;
     const int BN = t == 1 ? 128 : (t == 2 ? 64 : 32);
     const int KC = descs[0].math == ML_MATH_F16S ? 64 : 32;
     plan_splits(descs, n, BM, BN, KC, workspace_bytes > 0, workspace_bytes, ref_tiles, splits);
