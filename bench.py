@@ -667,7 +667,8 @@ def main():
                             f"{r['flops'] / 1e9 / max(ms, 1e-9):8.2f} TF/s {r['bytes'] / 1e6 / max(ms, 1e-9):9.1f} GB/s\n")
         agg = {}
         for r in recs:
-            a = agg.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0})
+            a = agg.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0, "staged_mb": 0.0})
+            a["staged_mb"] += r.get("staged_bytes", 0.0) / 1e6
             a["launches"] += 1
             a["ms"] += r["start"].elapsed_time(r["end"])
             a["gflop"] += r["flops"] / 1e9
@@ -723,6 +724,20 @@ def main():
                 roofline["mfma_peak"] = PEAK_F16_MFMA_TFLOPS
                 if mp:
                     roofline["mfma_peak_measured"] = mp["mfma_f16_TFLOPs"]
+            if dom == "conv1x1_h256_h" and d["staged_mb"] > 0:
+                # The half 256 x 256-tile kernel is bound by neither HBM nor the matrix pipe but by the per-CU L1 -> LDS request
+                # path its operands are staged through (rocprofv3 --pmc: TA busy 50-62 %, MFMA busy 32-45 %, request
+                # latencies short -- profiles/r04_h256_pmc.md).  `achieved` = bytes STAGED per launch (every 256-row tile: its
+                # 256 x K activations + 256 x K weights) / launch time; `peak` = 64 B/clk/CU (the vector L1's fill width) x
+                # 256 CUs x 2.4 GHz.  The HBM and MFMA figures of the same launches stay beside it.
+                l1_peak = 64.0 * 256 * 2.4
+                ach_l1 = d["staged_mb"] / d["ms"]
+                roofline.update(hbm={"achieved": roofline["achieved"], "peak": PEAK_HBM_GBS, "frac": roofline["frac"]},
+                                bound="l2_lds", achieved=round(ach_l1, 1), peak=round(l1_peak, 1), frac=round(ach_l1 / l1_peak, 4),
+                                bound_note="per-CU L1 -> LDS staging path (64 B/clk/CU nominal); PMC evidence: profiles/r04_h256_pmc.md",
+                                staged_bytes_per_launch=round(1e6 * d["staged_mb"] / d["launches"]))
+                roofline.pop("peak_measured", None)
+                roofline.pop("frac_of_measured", None)
 
     n_det = n_cand = []
     if rank == 0:

@@ -3,33 +3,41 @@
 // launches of M = 102 400, K / N = 1024 / 512 and 512 / 1024; thirdparty/classification_models/models/resnext.py:62-135).
 //
 // Why a second kernel beside conv1x1_pipe.hip: on half tensors a 128 x 128 tile with 64 x 64 per wave stages 32 KB for
-// 16 MFMAs per wave and chunk -- 8 LDS-direct loads (each ~60-100 cycles of issue) beside 512 cycles of matrix work, and
-// 64 B/clk/CU through the L2 -> LDS path, which is all that path has.  Here a block is 8 waves (2 per SIMD) on a
-// 256 x 256 tile, 128 x 64 per wave: the same 8 loads per wave and chunk feed 32 MFMAs, every staged byte is used for
-// twice the MACs, and the LDS-read traffic per MAC drops by a quarter.
-//   * K chunk = 64 halves = 128 bytes per row (full cache lines; XOR-swizzled 16-byte groups as in the other kernels),
-//     two 64 KB staging buffers (A 256 rows + B 256 rows), filled by `buffer_load_dwordx4 ... lds`;
-//   * the chunk stream crosses tile boundaries: a block is PERSISTENT, walks its tiles, and the first chunk of the next
-//     tile is in flight during the epilogue of the current one;
-//   * all N tiles of an M panel run at the same time on ONE XCD (blocks with equal blockIdx & 7), so the panel comes from
-//     beyond L2 once;
-//   * epilogue: accumulators -> wave-private LDS scratch (16 rows x 32 columns at a time) -> rows of 8 halves per lane,
-//     + bias + half residual, clamp, one rounding, 16-byte stores.
-// Measured against conv1x1_pipe_kernel<_Float16> (gpurun_out/r03_h256_ab.txt, 16 x 1280^2 ResNeXt-101 shapes, bit-identical
-// outputs): 1024->512 162 -> 132 us, 512->1024 + residual 188 -> 177, 512->256 176 -> 160, 256->512 + residual 265 -> 239,
-// 2048->1024 132 -> 123.  What holds it at ~810-870 TF: the K loop alone (stores ablated) runs at ~900 TF -- one
-// vmcnt(0) + barrier per chunk with the next chunk issued only one chunk ahead -- and a 128 KB tile drains at ~10 B/clk/CU
-// while the block's own MFMAs idle (one block per CU: nothing else to run).  Tried and measured no better: starting
-// blocks a quarter tile apart (s_sleep) so that epilogues overlap other blocks' K loops (132 -> 141 us on 1024->512,
-// 177 -> 172 on 512->1024 + residual); the next tile's chunk 1 issued before the stores with counted waits (kept: -2 %);
-// a ring of four 32-deep chunks with three in flight and counted waits (scripts/experiments/
-// r03_h256_ring4_bk32_with_stamps.patch: 132 -> 140 us -- 64-byte row pieces are half cache lines, twice the requests).
-// In-kernel s_memtime stamps of that experiment: per 64-deep chunk a wave spends ~1 950 cycles in its 32 MFMAs (the
-// SIMD's matrix pipe is saturated while it runs: two waves x 32 x 32 cycles = 2 048) and ~1 150-1 400 waiting for the
-// next chunk, whatever the prefetch depth: the block takes in 64 KB per ~3 100 cycles = 21 B/clk/CU, against the
-// ~33 B/clk/CU an MI355X CU gets from L2 through LDS-direct loads when it does nothing else (MI355X_MICROARCH.md,
-// "Indexed rows": 66-73 GB/s per CU) -- and full-rate MFMA on a 256 x 256 tile NEEDS 32 B/clk/CU.  The kernel is bound
-// by the L2 -> LDS path; padding the row pitch off a power of two changes nothing (not an L2-channel effect).
+// 16 MFMAs per wave and chunk.  Here a block is 8 waves (2 per SIMD) on a 256 x 256 tile, 128 x 64 per wave: the same 8
+// LDS-direct requests per wave and chunk feed 32 MFMAs, every staged byte is used for twice the MACs.
+//   * K chunk = 64 halves = 128 bytes per row (full cache lines; XOR-swizzled 16-byte groups as in the other kernels);
+//   * ROUND 4 -- LDS is a RING: three 32 KB slots for the activation (A) chunks and two for the weight (B) chunks, all
+//     160 KB of a CU.  While chunk c is multiplied the block requests B of chunk c + 1 and A of chunk c + 2; every wait is
+//     a counted `s_waitcnt vmcnt(N)` (requests retire in issue order).  Round 3 had two 64 KB buffers, requests one chunk
+//     ahead and `vmcnt(0)` per chunk;
+//   * a block is PERSISTENT over ONE contiguous range of rows (cut at multiples of 32: all ranges of a launch are equal
+//     +- 32 rows) and one N tile; the chunk stream crosses tile boundaries, so the next tile's first chunks are in flight
+//     during the epilogue.  The last tile of a range may be short; up to 128 rows it takes a LIGHT path -- the same chunk
+//     stream, but wave w multiplies columns 32 w .. + 31 by the Q <= 4 row groups that exist (Q MFMAs per 16-deep step
+//     instead of 8).  Round 3 dealt whole 256-row panels round-robin: 3.125 tile rounds cost 4;
+//   * all N tiles of a row range run at the same time on ONE XCD (blocks with equal blockIdx & 7): the rows come from
+//     beyond L2 once (TCC_EA0_RDREQ = the activation bytes, profiles/r04_h256_pmc.md);
+//   * epilogue: accumulators -> wave-private LDS scratch (16 rows x 32 columns at a time; it lives in the A slot the tile's
+//     last chunk freed) -> rows of 8 halves per lane, + bias + half residual, clamp, one rounding, 16-byte stores; B of the
+//     next tile's chunk 1 is requested BEFORE the stores, so two chunks of the next tile overlap the store drain.
+// Measured (16 x 1280^2 ResNeXt-101 shapes, outputs bit-identical to conv1x1_pipe_kernel<_Float16> and to round 3's kernel,
+// 0 mismatches in 30 repeated launches per shape; gpurun_out/r04e_h256_tail.txt, profiles/r04_h256_ab.txt), round 3 ->
+// ring -> ring + light tail:  1024->512  133.0 -> 124.7 -> 116.5 us;  512->1024 + residual  179.7 -> 160.2 -> 154.5;
+// 512->256  163.6 -> 150.1 -> 146.8;  256->512 + residual  245.2 -> 233.5 -> 234.0;  2048->1024  120.9 -> 114.9 -> 114.0;
+// 1024->2048 + residual  141.4 -> 139.5 -> 125.8;  the mode's 62 launches 10.3 -> 8.6 ms (667 -> 797 TF).
+// What bounds it now (profiles/r04_h256_pmc.md, profiles/r04_h256_request_ablations.txt): the matrix pipe is busy 45 % of the
+// launch (SQ_VALU_MFMA_BUSY_CYCLES = exactly the 32-cycle MFMAs the FLOPs need), the texture-address / L1 path 50-62 %
+// (TA_TA_BUSY: ~26 cycles per 1 KB LDS-direct request), waves wait 39 % of their cycles; request latencies are SHORT --
+// 430-500 cycles L1 -> L2 on average, 950-1 260 from L2 to the fabric -- so more requests in flight buy nothing more, and
+// with both operands through empty extents (same instructions, no bytes) the launch still takes 77 % of its time: barrier
+// + fragment-read + epilogue structure.  A 256 x 256 half tile moves 64 KB per chunk through a per-CU L1 path that
+// delivers ~30-39 B/clk while it is busy, i.e. ~1 700-2 200 cycles beside 2 048 cycles of MFMA: the two are of equal
+// size and only partly overlap.  Tried and measured no better in round 4: the 8 requests spread over every 2nd / 4th MFMA
+// (+-1 %); the two waves of a SIMD requesting in opposite halves of the chunk (+-2 %); `s_setprio 1` for waves 4-7
+// (+-1 %); a guard around every MFMA to skip the sub-tiles of a short tile (216 vs 134 us: branches in the matrix stream).
+// Round 3's notes that still hold: blocks started a quarter tile apart (s_sleep) no better; a ring of four 32-deep
+// chunks slower (64-byte row pieces = half cache lines, twice the requests); padding the row pitch off a power of two
+// changes nothing (not an L2-channel effect).
 // Numerics: fp16 products are exact in fp32, fp32 accumulation in k order per output, bias / residual / clamp in fp32 --
 // the same arithmetic as conv1x1_pipe_kernel<_Float16> (which chains 64-deep chunks the same way).
 #include <type_traits>

@@ -330,7 +330,12 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
         if which:
             name = "conv1x1_h256_h" if which == 2 else ("conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe")
     _log_launch(C.byref(d), 1, ws, shape)
-    with _Prof(name, flops, nbytes, shape):
+    with _Prof(name, flops, nbytes, shape) as prof:
+        if prof.on and name == "conv1x1_h256_h":
+            # bytes this launch stages through the CUs' L1 -> LDS path: every 256-row tile takes its 256 x K activation rows
+            # and the 256 x K weight rows of its N tile, 2 bytes each (what bounds that kernel: profiles/r04_h256_pmc.md)
+            M, N, K = d.B * d.Ho * d.Wo, d.cout, d.span
+            prof.rec["staged_bytes"] = float(-(-M // 256) * (N // 256) * 2 * 256 * K * 2)
         _lib.check(lib.ml_conv2d_multi_f32(C.byref(d), 1, _ptr(ws), ws.numel(), _stream()), "ml_conv2d_multi_f32")
     return ret
 
