@@ -826,6 +826,7 @@ conv_mfma_kernel(const MultiArgs args) {                                        
         if (p.out_f16) {
             // fp16-storage body behind this conv (the stem): same tile ownership, 4 halves (8 bytes) per lane and row
             _Float16 *oh = reinterpret_cast<_Float16 *>(p.out);
+            [[maybe_unused]] double gsh = 0.0, gqh = 0.0;
 #pragma unroll
             for (int i = 0; i < E_ROWS; ++i) {
                 const int m = m0 + r0 + i * ROWS_PER_PASS;
@@ -837,6 +838,25 @@ conv_mfma_kernel(const MultiArgs args) {                                        
                     }
                     const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                     *reinterpret_cast<f16x4 *>(oh + off + (size_t)i * ROWS_PER_PASS * cs) = hv;
+                    if constexpr (GNS && NT == 256) {
+                        // the GroupNorm behind a half head conv normalises the STORED (rounded) values: sum those
+                        const float h0 = (float)hv[0], h1 = (float)hv[1], h2 = (float)hv[2], h3 = (float)hv[3];
+                        gsh += (double)((h0 + h1) + (h2 + h3));
+                        gqh += (double)fmaf(h3, h3, fmaf(h2, h2, fmaf(h1, h1, h0 * h0)));
+                    }
+                }
+            }
+            if constexpr (GNS && NT == 256) {
+                if (p.gn_partials) {                           // (block-uniform; whole tiles only: launch_multi checks M % BM)
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        gsh += __shfl_down(gsh, o, 64);
+                        gqh += __shfl_down(gqh, o, 64);
+                    }
+                    if (lane == 0) {                           // one pair per WAVE, as in the fp32 form below
+                        p.gn_partials[2 * ((size_t)mt * 4 + wave)] = gsh;
+                        p.gn_partials[2 * ((size_t)mt * 4 + wave) + 1] = gqh;
+                    }
                 }
             }
         } else if (full && !late_res && !p.out_bstride) {
@@ -1130,8 +1150,8 @@ int launch_multi(const ml_conv2d_desc *descs, int n, void *workspace, long long 
         const long long slab_bytes = (long long)splits * P.MB * BM * d.n_pad * 4;
         if (d.gn_partials)
             ML_REQUIRE(GNS && splits == 1 && BN == 128 && d.cout == 128 && d.n_pad == 128 && M % BM == 0 && !d.residual &&
-                           !d.out_bstride && !d.out_f16 && !d.shuffle2x2 && d.act != ML_ACT_SIGMOID && !d.live &&
-                           host_out_vec_ok(d),
+                           !d.out_bstride && (!d.out_f16 || MATH == ML_MATH_F16S) && !d.shuffle2x2 && d.act != ML_ACT_SIGMOID &&
+                           !d.live && (d.out_f16 || host_out_vec_ok(d)),
                        "conv2d: gn_partials needs a launch that is neither narrowed nor split along K (ml_conv2d_gn_min_launch_tiles() "
                        "tiles of 128 x 128), cout = 128, whole 128-row tiles, no residual, and a dense fp32 destination on the "
                        "vector epilogue (out / bias 16-byte aligned, out_cstride and out_coff multiples of 4)");
@@ -1359,6 +1379,10 @@ extern "C" int ml_conv2d_multi_f32(const ml_conv2d_desc *descs_in, int32_t n_in,
     long long ref_tiles = -1;
     const int t = x3_adjust_tile(descs, n, narrow_tile_for_small_launch(descs, n, t0, workspace != nullptr, &ref_tiles));
     if (descs[0].math == ML_MATH_F16S) {
+        bool gns_h = false;
+        for (int i = 0; i < n; ++i) gns_h = gns_h || descs[i].gn_partials != nullptr;
+        ML_REQUIRE(!gns_h || t == 1, "conv2d: gn_partials needs the 128 x 128 kernel (a launch of ml_conv2d_gn_min_launch_tiles() tiles)");
+        if (gns_h) return launch_multi<2, 2, 2, 2, ML_MATH_F16S, true>(descs, n, workspace, workspace_bytes, s, ref_tiles);
         switch (t) {
             case 1: return launch_multi<2, 2, 2, 2, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);
             case 2: return launch_multi<2, 2, 2, 1, ML_MATH_F16S>(descs, n, workspace, workspace_bytes, s, ref_tiles);

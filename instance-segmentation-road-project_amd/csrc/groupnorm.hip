@@ -426,8 +426,8 @@ static int gn_multi(const ml_gn_desc *descs, int32_t n, void *workspace, int64_t
             ab += P.NG;
         } else if (d.partials) {
             // the producing conv summed its tiles (ml_conv2d_desc.gn_partials): no statistics pass over this tensor
-            ML_REQUIRE(d.n_partials >= 1 && d.n_partials <= 4096 && d.dtype == 0,
-                       "groupnorm_multi: problem %d: 1..4096 fp64 (sum, sum of squares) pairs per chunk, float tensors", i);
+            ML_REQUIRE(d.n_partials >= 1 && d.n_partials <= 4096,
+                       "groupnorm_multi: problem %d: 1..4096 fp64 (sum, sum of squares) pairs per chunk", i);
             const GnPlan plan = gn_plan(L, P.NG, W);
             P.S = plan.S; P.slice = plan.slice;
             P.ws = const_cast<double *>(d.partials);

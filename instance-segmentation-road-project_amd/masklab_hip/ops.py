@@ -285,7 +285,10 @@ def gn_fusable(out_shape, C_out, groups, dc, launch_tiles, dtype):
     B, Ho, Wo = out_shape
     hw = Ho * Wo
     p = dc.p
-    ok = (CONV_MATH in ("f32", "f32x3") and dtype == torch.float32 and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
+    # fp32 tensors on the exact / split-operand products, or half tensors (the heads of the fp16-storage mode: the sums are
+    # then of the ROUNDED values the conv stores, which is what that mode's GroupNorm statistics pass reads)
+    math_ok = (CONV_MATH in ("f32", "f32x3") and dtype == torch.float32) or (CONV_MATH == "f16s" and dtype == torch.float16)
+    ok = (math_ok and C_out == 128 and p.cout == 128 and p.n_pad == 128 and
           not p.shuffle2x2 and not p.group_cin_step and hw % 128 == 0 and hw % groups == 0 and (hw // groups) % 128 == 0 and
           launch_tiles >= _gn_min_launch_tiles())
     return 4 * ((hw // groups) // 128) if ok else 0

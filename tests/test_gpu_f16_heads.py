@@ -289,6 +289,48 @@ def test_heads_run_on_half_tensors(bt):
             assert float(np.abs(g.astype(np.float64) - r).max()) <= F16_MODEL_TOL, name
 
 
+def test_half_groupnorm_statistics_from_the_conv_epilogue():
+    """Round 4: ml_conv2d_desc.gn_partials on HALF tensors (the towers / decoder of the fp16-storage mode, reference
+    engine/layers/detection.py:120-125, semantic.py:205-213).  The half head conv also sums what it STORES -- the values
+    after the one rounding to half, which is what this mode's GroupNorm statistics pass reads -- per 128-row tile and
+    wave; GroupNorm then needs no statistics pass.  The conv's output is untouched, the pairs equal the fp64 sums of
+    the stored halves, conv -> GroupNorm gives the two-pass result to within one half step, and the tower helper
+    picks the form by itself (no gn_multi_stats launch for the big level)."""
+    from masklab_hip import _lib, ops, packing
+    from masklab_hip.keras_like import Conv2D
+    from masklab_hip.layers.detection import _TowerMixin
+    from masklab_hip.normalization import GroupNormalization
+    B, H, W = 3, 128, 128                         # 384 tiles; chunk = 1024 pixels = 8 tiles
+    x = to_half(rnd(B, H, W, 128))
+    w, b = rnd(3, 3, 128, 128, scale=0.03), rnd(128)
+    gamma, beta = RNG.uniform(0.5, 1.5, 128).astype(np.float32), rnd(128)
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    plain = ops.conv2d(dev(x), dc, act=_lib.ACT_RELU)
+    assert plain.dtype == torch.float16
+    want = host(ops.groupnorm_chunk(plain.clone(), dev(gamma), dev(beta), 16))
+    part = torch.full((B * H * W // 128, 4, 2), float("nan"), dtype=torch.float64, device="cuda")
+    y = ops.conv2d(dev(x), dc, act=_lib.ACT_RELU, gn_partials=part)
+    np.testing.assert_array_equal(host(y), host(plain))                     # the conv's own output is untouched
+    yh = host(y).astype(np.float64).reshape(-1, 128 * 128)                  # one row per 128-pixel tile
+    np.testing.assert_allclose(host(part)[..., 0].sum(1), yh.sum(1), rtol=1e-6)      # (four halves are folded in fp32 first)
+    np.testing.assert_allclose(host(part)[..., 1].sum(1), (yh * yh).sum(1), rtol=1e-6)
+    (got,) = ops.groupnorm_chunk_multi([dict(x=y, gamma=dev(gamma), beta=dev(beta), groups=16, out=y, partials=(part, 32))])
+    np.testing.assert_allclose(host(got).astype(np.float32), want.astype(np.float32), rtol=HALF_RTOL, atol=HALF_ATOL)
+    with pytest.raises(RuntimeError, match="gn_partials"):                  # 64 tiles: the library would narrow / split this launch
+        ops.conv2d(dev(x[:1, :64]), dc, act=_lib.ACT_RELU, gn_partials=part)
+    conv, gn = Conv2D(128, (3, 3), activation='relu', padding='same', name="t/conv0"), GroupNormalization(16, name="t/gn0")
+    conv.build((None, None, None, 128)); gn.build((None, None, None, 128))
+    wd = {"t/conv0/kernel": w, "t/conv0/bias": b, "t/gn0/gamma": gamma, "t/gn0/beta": beta}
+    conv.load_weights(wd, torch.device("cuda:0")); gn.load_weights(wd, torch.device("cuda:0"))
+    xs = [to_half(rnd(B, 128, 128, 128)), to_half(rnd(B, 64, 64, 128)), to_half(rnd(B, 16, 16, 128))]
+    ops.PROFILE = []
+    outs = _TowerMixin._run_towers_multi([[conv, gn]] * 3, [dev(v) for v in xs])
+    recs, ops.PROFILE = ops.PROFILE, None
+    for v, o in zip(xs, outs):
+        ref = T.relu(T.conv2d(h64(v), h64(w), b.astype(np.float64))).astype(np.float16).astype(np.float64)   # the stored conv output
+        close_half(host(o), T.group_norm(ref, gamma, beta, 16), atol=2e-3)
+
+
 def test_resnext101_1280_half_storage_detections_match_fp32_oracle():
     """BASELINE configs[4] at its size: ResNeXt-101, one 1280x1280 image, fp16 storage end to end, against the fp32
     oracle forward.  Float outputs within 3e-2; the DETECTIONS are the oracle's (DetectionIOUMetric precision = recall =

@@ -198,3 +198,31 @@ def test_conv1x1_h256_half_storage(cin, cout, hw, B, res, act):
         ref = ref + r[last].astype(np.float64)
     ref = ACT[act](ref).astype(np.float16)
     np.testing.assert_allclose(outs[5][last].astype(np.float32), ref.astype(np.float32), rtol=HALF_RTOL, atol=HALF_ATOL)
+
+
+@pytest.mark.parametrize("rows_per_block,ragged", [(512 + 32, 0), (512 + 64, 0), (512 + 96, 5), (512 + 128, 0), (512 + 160, 0),
+                                                    (512 + 224, 19), (256 + 32, 0)])
+def test_conv1x1_h256_row_ranges_short_tiles_and_repeats(rows_per_block, ragged):
+    """Round 4 form of csrc/conv1x1_h256.hip: every block walks ONE contiguous range of rows (all ranges equal +- 32
+    rows) through a ring of 3 activation + 2 weight LDS slots with counted waits, and a short last tile of up to 128
+    rows takes the light path (Q = 1..4 row groups of 32), longer ones the full stream on zero-filled rows.  M is chosen
+    so that each of the 128 ranges of an N = 512 launch (2 N tiles, 128 blocks each on a 256-CU part) ends in the given
+    tail; `ragged` rows are cut off the end (the last range's tail is then not a multiple of 32).  Bit for bit against
+    conv1x1_pipe_kernel<_Float16>, five launches each: a staged slot read before its request has landed shows up as RARE
+    wrong tiles, not as a consistent error."""
+    from masklab_hip import _lib, ops, packing
+    cin, cout = 256, 512                         # 4 chunks per tile (the shortest K the kernel takes), 2 N tiles
+    M = 128 * rows_per_block - ragged
+    x = to_half(rnd(1, 1, M, cin))
+    w, b = rnd(1, 1, cin, cout, scale=1.0 / np.sqrt(cin)), rnd(cout)
+    r = to_half(rnd(1, 1, M, cout))
+    xd, rd = dev(x), dev(r)
+    ref = ops.conv2d(xd, ops.DeviceConv(packing.pack_dense(w, b, tile=4), "cuda"), padding="valid", act=_lib.ACT_RELU, residual=rd)
+    dc5 = ops.DeviceConv(packing.pack_dense(w, b, tile=5), "cuda")
+    for rep in range(5):
+        got = ops.conv2d(xd, dc5, padding="valid", act=_lib.ACT_RELU, residual=rd)
+        assert torch.equal(got, ref), f"launch {rep}: {int((got != ref).sum())} elements differ"
+    sub = slice(M - 700, M)                      # the oracle on the last rows (short tile + ragged end)
+    want = T.conv2d(x[:, :, sub].astype(np.float64), h64(w), b.astype(np.float64), 1, "valid", 1) + r[:, :, sub].astype(np.float64)
+    np.testing.assert_allclose(host(ref)[:, :, sub].astype(np.float32), np.maximum(want, 0).astype(np.float16).astype(np.float32),
+                               rtol=HALF_RTOL, atol=HALF_ATOL)
