@@ -728,13 +728,18 @@ def main():
                 # The half 256 x 256-tile kernel is bound by neither HBM nor the matrix pipe but by the per-CU L1 -> LDS request
                 # path its operands are staged through (rocprofv3 --pmc: TA busy 50-62 %, MFMA busy 32-45 %, request
                 # latencies short -- profiles/r04_h256_pmc.md).  `achieved` = bytes STAGED per launch (every 256-row tile: its
-                # 256 x K activations + 256 x K weights) / launch time; `peak` = 64 B/clk/CU (the vector L1's fill width) x
-                # 256 CUs x 2.4 GHz.  The HBM and MFMA figures of the same launches stay beside it.
-                l1_peak = 64.0 * 256 * 2.4
+                # 256 x K activations + 256 x K weights) / launch time.  The HBM and MFMA figures of the same launches stay
+                # beside it.
+                # peak: what LDS-direct loads deliver into LDS from L2 with every CU streaming and nothing else going on --
+                # 66-73 GB/s per CU, 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, "Indexed rows: gather into LDS", rows
+                # served from the XCD's L2); the L1's nominal fill width (64 B/clk/CU) is twice that and never observed
+                l1_peak = 18800.0
                 ach_l1 = d["staged_mb"] / d["ms"]
                 roofline.update(hbm={"achieved": roofline["achieved"], "peak": PEAK_HBM_GBS, "frac": roofline["frac"]},
                                 bound="l2_lds", achieved=round(ach_l1, 1), peak=round(l1_peak, 1), frac=round(ach_l1 / l1_peak, 4),
-                                bound_note="per-CU L1 -> LDS staging path (64 B/clk/CU nominal); PMC evidence: profiles/r04_h256_pmc.md",
+                                bound_note="L2 -> LDS staging path: peak = 18.8 TB/s, the guide's measured chip-wide rate of LDS-direct "
+                                           "loads served from L2; rocprofv3 --pmc on this kernel: TA busy 50-62 %, matrix pipe busy "
+                                           "32-45 %, the two barely overlapping (profiles/r04_h256_pmc.md)",
                                 staged_bytes_per_launch=round(1e6 * d["staged_mb"] / d["launches"]))
                 roofline.pop("peak_measured", None)
                 roofline.pop("frac_of_measured", None)

@@ -327,8 +327,11 @@ def test_half_groupnorm_statistics_from_the_conv_epilogue():
     outs = _TowerMixin._run_towers_multi([[conv, gn]] * 3, [dev(v) for v in xs])
     recs, ops.PROFILE = ops.PROFILE, None
     for v, o in zip(xs, outs):
+        # two roundings between the oracle and the result (the conv's store, whose fp32 sum may round the other way in a
+        # few elements, and the GroupNorm's store): two half steps
         ref = T.relu(T.conv2d(h64(v), h64(w), b.astype(np.float64))).astype(np.float16).astype(np.float64)   # the stored conv output
-        close_half(host(o), T.group_norm(ref, gamma, beta, 16), atol=2e-3)
+        np.testing.assert_allclose(host(o).astype(np.float32), T.group_norm(ref, gamma, beta, 16).astype(np.float32),
+                                   rtol=2 * HALF_RTOL, atol=2e-3)
 
 
 def test_resnext101_1280_half_storage_detections_match_fp32_oracle():
