@@ -167,7 +167,8 @@ int ml_gconv3x3_f32(const float *in, const float *wgt, const float *bias, float 
                     int32_t stride, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
 
 /* The same on fp16 tensors (in / out IEEE half, weights / bias / arithmetic fp32): the grouped conv of an
- * fp16-STORAGE ResNeXt body (BASELINE config 5).                                                    */
+ * fp16-STORAGE ResNeXt body (BASELINE config 5).  Also c = 32 (the last stage, filters = 1024: two
+ * v_mfma_f32_32x32x16_f16 per tap contract a group).                                                 */
 int ml_gconv3x3_f16(const void *in, const float *wgt, const float *bias, void *out,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c, int32_t Ho, int32_t Wo,
                     int32_t stride, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);

@@ -312,6 +312,10 @@ class GroupedConv2D(Conv2D):
             self.dev = True
         else:
             self.dev = ops.DeviceConv(packing.pack_grouped(k, self.groups, b), device)
+            # half tensors (fp16-storage mode) with groups of 32 run csrc/gconv_mfma4.hip's 32x32x16 form: the [C][9][c]
+            # packing of the small-group kernels, made on first use
+            self._k32, self._b32, self._dev32, self.wgt4, self.bias4 = (k, b, device, None, None) if self.c == 32 and \
+                self.filters % 64 == 0 else (None, None, None, None, None)
 
     def call(self, x, **kwargs):
         if self.dev is None:
@@ -321,11 +325,16 @@ class GroupedConv2D(Conv2D):
 
 def grouped3x3(layer, x):
     """The grouped 3x3 of a ResNeXt block on whichever kernel fits its group width; in the fp16-storage mode (half
-    `x`) the 32-channel groups of the last stage -- a small tensor on the dense kernel -- go through an fp32 copy of
-    the input and come back as half."""
+    `x`) the 32-channel groups of the last stage run on the 32x32x16 form of the grouped kernel (round 4; before: an fp32
+    copy of the input through the dense kernel)."""
     import torch
     act = _lib.ACT_BY_NAME[layer.activation]
     if layer.use_mfma4:
+        return ops.gconv3x3(x, layer.wgt4, layer.bias4, layer.c, stride=layer.strides[0], padding=layer.padding, act=act)
+    if x.dtype == torch.float16 and getattr(layer, "_k32", None) is not None:
+        if layer.wgt4 is None:
+            layer.wgt4 = torch.from_numpy(packing.pack_grouped_mfma4(layer._k32, layer.groups)).to(layer._dev32)
+            layer.bias4 = None if layer._b32 is None else torch.from_numpy(np.ascontiguousarray(layer._b32, np.float32)).to(layer._dev32)
         return ops.gconv3x3(x, layer.wgt4, layer.bias4, layer.c, stride=layer.strides[0], padding=layer.padding, act=act)
     if x.dtype == torch.float16:
         return ops.conv2d(ops.cast_h2f(x), layer.dev, stride=layer.strides[0], padding=layer.padding, act=act,

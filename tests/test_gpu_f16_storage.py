@@ -85,10 +85,11 @@ def test_conv1x1_half_storage(cin, cout, hw, B, res, act, stride):
 
 @pytest.mark.parametrize("c,C,stride,hw", [(4, 128, 1, (24, 20)), (8, 256, 2, (20, 24)), (16, 512, 1, (16, 16)),
                                            (4, 128, 2, (17, 19)), (8, 256, 1, (9, 30)), (16, 512, 2, (19, 21)),
-                                           (16, 1024, 1, (5, 7))])
+                                           (16, 1024, 1, (5, 7)), (32, 1024, 1, (40, 40)), (32, 1024, 2, (21, 19)),
+                                           (32, 128, 1, (9, 13))])
 def test_grouped3x3_half_storage(c, C, stride, hw):
     """fp16 tensors run the grouped 3x3 on the fp16 matrix instructions (v_mfma_f32_4x4x4_16B_f16 for c = 4 / 8,
-    v_mfma_f32_16x16x16_f16 for c = 16): activations are the tensor's own halves, the kernel is rounded to half once per
+    v_mfma_f32_16x16x16_f16 for c = 16, v_mfma_f32_32x32x16_f16 for c = 32): activations are the tensor's own halves, the kernel is rounded to half once per
     block, products exact, fp32 accumulation -- so the oracle gets BOTH operands half-rounded"""
     from masklab_hip import _lib, ops, packing
     groups = C // c
