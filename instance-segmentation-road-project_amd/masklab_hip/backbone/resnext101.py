@@ -62,6 +62,9 @@ class SlicedGroupConv2D(Conv2D):
             self.dev = True
         else:
             self.dev = ops.DeviceConv(packing.pack_grouped(dw, self.groups, b), device)
+            # (half tensors with groups of 32: keras_like.grouped3x3 packs for the 32x32x16 grouped kernel on first use)
+            self._k32, self._b32, self._dev32, self.wgt4, self.bias4 = (dw, b, device, None, None) if self.c == 32 and \
+                self.filters % 64 == 0 else (None, None, None, None, None)
 
     def call(self, x, **kwargs):
         if self.dev is None:
