@@ -474,15 +474,15 @@ gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
 //   A: lane (m = l & 31, q = l >> 5) holds W[out m][in 16 kh + 8 q .. + 7]     (9 taps x 2 k-halves x 8 halves, in registers)
 //   B: lane (p = l & 31, q)          holds X[pixel p][in 16 kh + 8 q .. + 7]    (one ds_read_b128 per tap and k-half)
 //   D: lane (p, q) holds out channels (e & 3) + 8 (e >> 2) + 4 q of pixel p     (four 8-byte stores)
-// Block = 8 x 8 output pixels x one 64-channel slab (two groups): wave w multiplies group w & 1 by the 32 pixels of tile
-// rows 4 (w >> 1) .. + 3.  (Round 3 ran this stage through an fp32 copy of the input on the dense kernel's 32-wide
+// Block = a COLUMN of 8 x 8-pixel tiles x one 64-channel slab (two groups): wave w multiplies group w & 1 by the 32 pixels of
+// tile rows 4 (w >> 1) .. + 3, tile after tile, its weights staying in registers.  (Round 3 ran this stage through an fp32 copy of the input on the dense kernel's 32-wide
 // block-diagonal tiles: a cast launch + a conv on operands converted in registers.)
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 
 template <int STRIDE>
 __global__ void __launch_bounds__(256)
 gconv32h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_y) {
     constexpr int TH = 8, TW = 8;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
@@ -492,30 +492,18 @@ gconv32h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
     constexpr int NLD = (NPIX + PPP - 1) / PPP;
     extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PS16H]  (144 B per pixel: 32 consecutive pixels x 16 B hit distinct bank groups)
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // one block = one COLUMN of 8 x 8 tiles of one image and slab: the group's 9 x 32 x 32 weights (36 KB per wave, more than
+    // a tile's 12.8 KB of input) are fetched once and stay in registers while the block walks down the column
+    const int tx = blockIdx.x;
     const int cs0 = blockIdx.y * CS;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int ox0 = tx * TW;
+    const int ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p32 = lane & 31, q = lane >> 5;
     const int grp = wave & 1, half = wave >> 1;
 
-    f16x8g stage[NLD];
-    {
-        const int cN = (tid % TPP) * 8;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int p = tid / TPP + PPP * i;
-            const int py = p / TWIN, px = p - py * TWIN;
-            const int iy = iy0 + py, ix = ix0 + px;
-            f16x8g v = {};
-            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
-            stage[i] = v;
-        }
-    }
     // weights of group `grp` of the slab: out channel cs0 + 32 grp + p32, tap t, in channels 16 kh + 8 q .. + 7
     f16x8h wv[9][2];
     {
@@ -530,43 +518,59 @@ gconv32h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
                                    (_Float16)w1[0], (_Float16)w1[1], (_Float16)w1[2], (_Float16)w1[3]};
             }
     }
-    {
-        const int cN = (tid % TPP) * 8;
+    f32x4 bv[4];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4)
+        bv[e4] = bias ? *reinterpret_cast<const f32x4 *>(bias + cs0 + grp * 32 + 8 * e4 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int py = 4 * half + (p32 >> 3), px = p32 & 7;             // this lane's output pixel inside a tile
+    const int pbase = ((py * STRIDE) * TWIN + px * STRIDE) * PS16H + grp * 32 + 8 * q;
+    const int cN = (tid % TPP) * 8;
+
+    for (int ty = 0; ty < tiles_y; ++ty) {
+        const int oy0 = ty * TH;
+        const int iy0 = oy0 * STRIDE - pad_t;
+        f16x8g stage[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid / TPP + PPP * i;
+            const int ppy = p / TWIN, ppx = p - ppy * TWIN;
+            const int iy = iy0 + ppy, ix = ix0 + ppx;
+            f16x8g v = {};
+            if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+            stage[i] = v;
+        }
+        if (ty > 0) __syncthreads();                                // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid / TPP + PPP * i;
             if (p < NPIX) *reinterpret_cast<f16x8g *>(tileh + p * PS16H + cN) = stage[i];
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    const int py = 4 * half + (p32 >> 3), px = p32 & 7;             // this lane's output pixel inside the tile
-    const int pbase = ((py * STRIDE) * TWIN + px * STRIDE) * PS16H + grp * 32 + 8 * q;
-    f32x16 acc;
+        f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * TWIN + (t % 3)) * PS16H;
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * TWIN + (t % 3)) * PS16H;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const f16x8h xv = *reinterpret_cast<const f16x8h *>(tileh + pbase + toff + kh * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[t][kh], xv, acc, 0, 0, 0);
+            for (int kh = 0; kh < 2; ++kh) {
+                const f16x8h xv = *reinterpret_cast<const f16x8h *>(tileh + pbase + toff + kh * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[t][kh], xv, acc, 0, 0, 0);
+            }
         }
-    }
-
-    const int oy = oy0 + py, ox = ox0 + px;
-    if (oy >= Ho || ox >= Wo) return;
-    _Float16 *orow = out + ((long long)(b * Ho + oy) * Wo + ox) * C + cs0 + grp * 32;
+        const int oy = oy0 + py, ox = ox0 + px;
+        if (oy < Ho && ox < Wo) {
+            _Float16 *orow = out + ((long long)(b * Ho + oy) * Wo + ox) * C + cs0 + grp * 32;
 #pragma unroll
-    for (int e4 = 0; e4 < 4; ++e4) {
-        const int oc = 8 * e4 + 4 * q;                              // channels oc .. oc + 3 of the group: registers 4 e4 .. + 3
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + cs0 + grp * 32 + oc);
-        f32x4 r;
+            for (int e4 = 0; e4 < 4; ++e4) {                        // channels 8 e4 + 4 q .. + 3 of the group: registers 4 e4 .. + 3
+                f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(acc[4 * e4 + e] + bv[e], act);
-        store4<_Float16>(orow + oc, r);
+                for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(acc[4 * e4 + e] + bv[e4][e], act);
+                store4<_Float16>(orow + 8 * e4 + 4 * q, r);
+            }
+        }
     }
 }
 
@@ -579,8 +583,8 @@ int launch32h(const _Float16 *in, const float *wgt, const float *bias, _Float16 
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + 7) / 8, tiles_y = (Ho + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho, Wo,
-                       pad_t, pad_l, act, tiles_x);
+    hipLaunchKernelGGL(kern, dim3(tiles_x, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho, Wo,
+                       pad_t, pad_l, act, tiles_y);
     ML_CHECK_LAUNCH("gconv3x3");
     return ML_OK;
 }

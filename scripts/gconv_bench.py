@@ -20,7 +20,8 @@ SHAPES = {
             ("r50 s3 64^2 C512 c16", 8, 64, 64, 512, 16, 1)],
     "f16": [("r101 s1 320^2 C128 c4", 16, 320, 320, 128, 4, 1), ("r101 s2b1 320^2 C256 c8 s2", 16, 320, 320, 256, 8, 2),
             ("r101 s2 160^2 C256 c8", 16, 160, 160, 256, 8, 1), ("r101 s3b1 160^2 C512 c16 s2", 16, 160, 160, 512, 16, 2),
-            ("r101 s3 80^2 C512 c16", 16, 80, 80, 512, 16, 1)],
+            ("r101 s3 80^2 C512 c16", 16, 80, 80, 512, 16, 1), ("r101 s4b1 80^2 C1024 c32 s2", 16, 80, 80, 1024, 32, 2),
+            ("r101 s4 40^2 C1024 c32", 16, 40, 40, 1024, 32, 1), ("r50 s4 32^2 C1024 c32 (8 img)", 8, 32, 32, 1024, 32, 1)],
 }
 
 
