@@ -79,7 +79,7 @@ WORKLOADS = {
     "resnext101_full_b16_1280_x3": ("resnext101", 16, 1280, 1280),   # configs[4] shape, fp32 tensors, f32x3
 }
 # which roofline binds each kernel class
-HBM_BOUND = ("groupnorm", "gconv3x3", "dwconv3x3", "maxpool", "resize", "preprocess", "detection", "cast", "trim",
+HBM_BOUND = ("groupnorm", "gconv3x3", "dwconv3x3", "maxpool", "stem7x7s2_pool", "resize", "preprocess", "detection", "cast", "trim",
              "semantic_smoothing", "crop_pad", "instance_summary")
 
 

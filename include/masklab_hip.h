@@ -38,7 +38,7 @@ extern "C" {
 enum { ML_ACT_NONE = 0, ML_ACT_RELU = 1, ML_ACT_RELU6 = 2, ML_ACT_SIGMOID = 3 };
 enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
 
-#define ML_ABI_VERSION 6              /* 2: ml_conv2d_desc gained `math` / `reserved0`
+#define ML_ABI_VERSION 7              /* 2: ml_conv2d_desc gained `math` / `reserved0`
                                          3: detection gather payload, mask_distribute level_max,
                                             fp16 tensor storage
                                          4: fp16 storage in the heads: ML_MATH_F16S on the generic conv,
@@ -47,7 +47,8 @@ enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
                                          5: fixed-capacity RoI batches (`live`) in conv / GroupNorm / RoI crop /
                                             mask-head tail descriptors, ml_mold_levels_f32
                                          6: ml_conv2d_launch_splits, ml_conv2d_gn_min_launch_tiles (reporting /
-                                            the size rule of gn_partials asked of the library, not restated by callers) */
+                                            the size rule of gn_partials asked of the library, not restated by callers)
+                                         7: ml_stem7x7s2_pool_f16; ml_gconv3x3_f16 takes groups of 32 channels        */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -197,6 +198,16 @@ int ml_dwconv3x3_f16(const void *in, const float *wgt, const float *bias, void *
                      int32_t out_cstride, int32_t out_coff, int32_t Ho, int32_t Wo,
                      int32_t stride, int32_t dil, int32_t pad_t, int32_t pad_l, int32_t act, void *stream);
 int ml_global_mean_f16(const void *in, void *out, int32_t B, int32_t HW, int32_t C, void *stream);
+
+/* The ResNeXt stem of the fp16-storage mode in one pass (engine/backbone/ResNext.py:343-352; thirdparty/classification_models/
+ * models/resnext.py:193-197): ZeroPadding2D(3) + Conv2D(64, 7x7, stride 2, BatchNorm folded) + ReLU + ZeroPadding2D(1) +
+ * MaxPooling2D(3, 2).  image: fp32 NHWC4 [B,H,W,4] (ml_preprocess_f32 with out_c = 4); wgt_h: IEEE half [64][7][8][4] =
+ * the row-span packing of the stem (k = kernel row * 32 + pixel * 4 + channel, 8th pixel / 4th channel zero) rounded to
+ * half; bias fp32 [64] or NULL; out: IEEE half [B,Hp,Wp,64].  Operands rounded to half, fp32 accumulation from the bias,
+ * one rounding: bit-identical to ml_conv2d_f32 (ML_MATH_F16, out_f16) followed by ml_maxpool3x3s2_f16, without the
+ * un-pooled map (839 MB at 16 x 1280^2) ever reaching memory.                                                     */
+int ml_stem7x7s2_pool_f16(const float *image, const void *wgt_h, const float *bias, void *out, int32_t B, int32_t H,
+                          int32_t W, int32_t Hp, int32_t Wp, void *stream);
 
 /* ---------------------------------------------------------------- fused mask-head tail
  * Conv2DTranspose(C_mid, (2,2), (2,2)) + bias + act_mid followed by Conv2D(ncls, (1,1)) + bias + act_out in one

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # resolved path into its JSON line.
 LIB_PATH = os.path.join(_HERE, "libmasklab_hip.so")
 
-ABI_VERSION = 6          # ML_ABI_VERSION of include/masklab_hip.h
+ABI_VERSION = 7          # ML_ABI_VERSION of include/masklab_hip.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "relu6": ACT_RELU6,
                "sigmoid": ACT_SIGMOID}
@@ -79,6 +79,7 @@ SIGNATURES = {
     "ml_gconv3x3_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_gconv3x3_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "ml_maxpool3x3s2_f16": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
+    "ml_stem7x7s2_pool_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
     "ml_subsample2_f16": (C.c_int, [_vp, _vp] + [_i32] * 4 + [_vp]),
     "ml_cast_f16_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_cast_f32_to_f16": (C.c_int, [_vp, _vp, _i64, _vp]),

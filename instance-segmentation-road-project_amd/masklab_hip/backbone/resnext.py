@@ -87,9 +87,13 @@ class ResNeXt50(Layer):
         import torch
         half = ops.half_storage()            # fp16-storage mode: the body's tensors AND its taps are IEEE half
         taps = {}
-        x = self.conv1(x, out_dtype=torch.float16 if half else None)
-        taps["C1"] = x
-        x = ops.maxpool3x3s2(x, pad=1)                     # pool1_pad + pool1_pool (:351-352)
+        if half and "C1" not in wanted and self.conv1.dev is not None:
+            # fp16-storage mode and nobody asked for the un-pooled stem output: stem + pool in one pass (csrc/stem_h.hip)
+            x = ops.stem_pool_h(x, self.conv1.dev)
+        else:
+            x = self.conv1(x, out_dtype=torch.float16 if half else None)
+            taps["C1"] = x
+            x = ops.maxpool3x3s2(x, pad=1)                     # pool1_pad + pool1_pool (:351-352)
         last = max(int(t[1]) for t in wanted)
         for tap, stage in zip(("C2", "C3", "C4", "C5"), self.stages):
             for blk in stage:

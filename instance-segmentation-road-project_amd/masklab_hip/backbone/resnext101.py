@@ -158,9 +158,12 @@ class ResNeXt101(Layer):
         import torch
         half = ops.half_storage()            # fp16-storage mode: the body's tensors AND its taps are IEEE half
         taps = {}
-        x = self.conv0(x, out_dtype=torch.float16 if half else None)
-        taps["C1"] = x
-        x = ops.maxpool3x3s2(x, pad=1)
+        if half and "C1" not in wanted and self.conv0.dev is not None:
+            x = ops.stem_pool_h(x, self.conv0.dev)        # stem + pool in one pass (csrc/stem_h.hip): fp16-storage mode only
+        else:
+            x = self.conv0(x, out_dtype=torch.float16 if half else None)
+            taps["C1"] = x
+            x = ops.maxpool3x3s2(x, pad=1)
         last = max(int(t[1]) for t in wanted)
         for tap, units in zip(("C2", "C3", "C4", "C5"), self.stages):
             for u in units:

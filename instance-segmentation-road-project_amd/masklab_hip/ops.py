@@ -461,6 +461,29 @@ def dwconv3x3(x, wgt, bias, stride=1, padding="same", dilation=1, act=_lib.ACT_N
     return out
 
 
+def stem_pool_h(x4, dc: "DeviceConv"):
+    """ml_stem7x7s2_pool_f16: the ResNeXt stem (7x7 stride-2 conv + folded BN + ReLU) and the 3x3 stride-2 max-pool behind
+    it in ONE kernel, fp32 NHWC4 image in, half pooled map out -- the fp16-storage mode only (the un-pooled stem output is
+    never written).  `dc` = the stem's row-span DeviceConv; its weights rounded to half are made on first use."""
+    lib = _lib.load()
+    _require_dev(x4, "x4")
+    p = dc.p
+    B, H, W, c4 = x4.shape
+    if x4.dtype != torch.float32 or c4 != 4 or p.cpp_shift == 30 or p.KH != 7 or p.span_pad != 32 or p.cout != 64 or p.n_pad != 64:
+        raise ValueError("stem_pool_h: needs the fp32 NHWC4 image and the 7x7 / 64-filter row-span stem packing")
+    wh = getattr(dc, "_stem_wgt_h", None)
+    if wh is None:
+        wh = dc._stem_wgt_h = torch.from_numpy(np.ascontiguousarray(p.wgt, np.float32).astype(np.float16)).to(x4.device)
+    Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
+    out = torch.empty((B, Hp, Wp, 64), dtype=torch.float16, device=x4.device)
+    with _Prof("stem7x7s2_pool_h", 2.0 * B * Hc * Wc * 64 * 147, 16 * B * H * W + 2 * out.numel() + 2 * 64 * 224,
+               f"B={B} HxW={H}x{W} -> {Hp}x{Wp}x64"):
+        _lib.check(lib.ml_stem7x7s2_pool_f16(_ptr(x4), _ptr(wh), _ptr(dc.bias), _ptr(out), B, H, W, Hp, Wp, _stream()),
+                   "ml_stem7x7s2_pool_f16")
+    return out
+
+
 def maxpool3x3s2(x, pad=1):
     lib = _lib.load()
     _require_dev(x, "x")

@@ -52,7 +52,7 @@ def test_bench_json_contract_single_rank():
     assert d["cpu_baseline"]["kind"] in ("port", "port (torch-CPU convs)")        # the oracle, NumPy-only or with oneDNN convs
     assert any("torch-CPU convs" in k for k in d["cpu_baseline"]["images_per_sec"])   # both ways are timed and reported
     assert d["parity"]["timed_forward"]["loc_pred_and_seg_pred_bit_identical_to_the_checked_forward"] is True
-    assert d["library"]["path"].endswith("masklab_hip/libmasklab_hip.so") and d["library"]["abi_version"] == 6
+    assert d["library"]["path"].endswith("masklab_hip/libmasklab_hip.so") and d["library"]["abi_version"] == 7
     for key in ("cpu_model", "blas_threads", "images_per_sec"):
         assert key in d["cpu_baseline"], key
     assert any("all threads" in k and "torch" not in k for k in d["cpu_baseline"]["images_per_sec"])     # the NumPy-only way

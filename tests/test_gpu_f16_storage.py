@@ -113,6 +113,26 @@ def test_half_byte_movers_are_exact():
     np.testing.assert_array_equal(host(ops.cast_h2f(dev(y))), y.astype(np.float32))
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 41), (3, 130, 70)])
+def test_fused_stem_and_pool_equals_the_two_kernels(B, H, W):
+    """csrc/stem_h.hip (round 4): the fp16-storage stem -- 7x7 stride-2 conv + folded BN + ReLU -- and the 3x3 stride-2
+    max-pool in ONE kernel (reference engine/backbone/ResNext.py:343-352).  Same operands (image and weights rounded to half),
+    same k order, bias first, one rounding, exact max: BIT-identical to the unfused pair; and within one half step of the
+    oracle.  Odd sizes exercise the zero padding on every side and partial pooled tiles."""
+    from masklab_hip import _lib, ops, packing
+    x = rnd(B, H, W, 3)
+    x4 = np.concatenate([x, np.zeros_like(x[..., :1])], -1)
+    w, b = rnd(7, 7, 3, 64, scale=0.08), rnd(64)
+    dc = ops.DeviceConv(packing.pack_rowspan(w, b), "cuda")
+    two = ops.maxpool3x3s2(ops.conv2d(dev(x4), dc, stride=2, padding=((3, 3), (3, 3)), act=_lib.ACT_RELU, out_dtype=torch.float16), pad=1)
+    one = ops.stem_pool_h(dev(x4), dc)
+    assert one.dtype == torch.float16 and one.shape == two.shape
+    np.testing.assert_array_equal(host(one), host(two))
+    conv = T.relu(T.conv2d(h64(x), h64(w), b.astype(np.float64), 2, ((3, 3), (3, 3)))).astype(np.float16).astype(np.float64)
+    ref = T.max_pool(np.pad(conv, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)
+    np.testing.assert_allclose(host(one).astype(np.float32), ref.astype(np.float32), rtol=HALF_RTOL, atol=HALF_ATOL)
+
+
 def test_stem_writes_half():
     """the 7x7 stride-2 stem (fp32 NHWC4 image in, operands rounded to half in the kernel) storing half"""
     from masklab_hip import _lib, ops, packing
