@@ -15,7 +15,9 @@
 //     followed by maxpool3x3s2_f16.
 //   * transposed product: A = weights (rows = output channels), B = pixels, so lane (p, q) ends up with four runs of four
 //     consecutive channels of ITS conv pixel -> 8-byte writes into the conv tile in LDS.
-//   * a block walks a ROW of pooled tiles with the 64 x 224 weights (28 halves-fragments per lane) resident in registers.
+//   * a block walks a ROW of pooled tiles; wave w multiplies output channels 32 (w >> 1) .. + 31 by every other set of 32
+//     conv pixels, its 14 weight fragments resident in registers, and the next tile's input pixels are fetched into
+//     registers under the current tile's MFMAs (two barriers per tile).
 #include "common.h"
 
 namespace {
@@ -45,70 +47,90 @@ stem_pool_h_kernel(const float *__restrict__ img, const _Float16 *__restrict__ w
     const int p32 = lane & 31, q = lane >> 5;
     const int ty = blockIdx.x, b = blockIdx.y;
     const int py0 = ty * PTH;
+    const int cy0 = 2 * py0 - 1;                                        // conv row of tile-local row 0
+    const int iy0 = 2 * cy0 - 3;                                        // input row of tile-local row 0
+    // wave w multiplies the 32 output channels 32 (w >> 1) .. by the conv-pixel sets (w & 1), (w & 1) + 2, ...: 5 sets x 14
+    // MFMAs each, and only 14 weight fragments (56 registers) per lane -- room for the next tile's input in registers
+    const int nt = wave >> 1, s0 = wave & 1;
 
     // weights: A fragments.  lane (m = p32, q): output channel 32 nt + m, k = 16 s + 8 q .. + 7
-    f16x8 wv[2][14];
+    f16x8 wv[14];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int s = 0; s < 14; ++s)
-            wv[nt][s] = *reinterpret_cast<const f16x8 *>(wgt + (nt * 32 + p32) * 224 + s * 16 + q * 8);
+    for (int s = 0; s < 14; ++s) wv[s] = *reinterpret_cast<const f16x8 *>(wgt + (nt * 32 + p32) * 224 + s * 16 + q * 8);
     // bias of the channels this lane's accumulator registers hold: 32 nt + (e & 3) + 8 (e >> 2) + 4 q
-    float bv[2][16];
+    float bv[16];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) bv[nt][e] = bias ? bias[nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * q] : 0.f;
+    for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * q] : 0.f;
 
+    // ---- this thread's share of an input tile: elements tid + 256 j of the [IR][ICP] pixel grid (fp32 NHWC4 -> half)
+    constexpr int NIN = (IR * ICP + 255) / 256;                         // 7
+    int in_r[NIN], in_c[NIN];
+    long long in_off[NIN];                                              // float offset of (row, column 0 of tile 0)
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        const int i = tid + 256 * j;
+        in_r[j] = i / ICP;
+        in_c[j] = i - in_r[j] * ICP;
+        const int iy = iy0 + in_r[j];
+        const bool row_ok = i < IR * ICP && (unsigned)iy < (unsigned)H;
+        in_off[j] = row_ok ? ((long long)(b * H + iy) * W) * 4 : -1;
+    }
+    f32x4 stage[NIN];
+    auto fetch = [&](int tx) __attribute__((always_inline)) {         // global -> registers (zeros outside the image)
+        const int ix0 = 2 * (2 * tx * PTW - 1) - 3;
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int ix = ix0 + in_c[j];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in_off[j] >= 0 && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4 *>(img + in_off[j] + (long long)ix * 4);
+            stage[j] = v;
+        }
+    };
+    auto deposit = [&]() __attribute__((always_inline)) {              // registers -> LDS, rounded to half
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int i = tid + 256 * j;
+            if (i < IR * ICP)
+                *reinterpret_cast<f16x4 *>(tin + i * 4) = f16x4{(_Float16)stage[j][0], (_Float16)stage[j][1], (_Float16)stage[j][2], (_Float16)stage[j][3]};
+        }
+    };
+
+    fetch(0);
+    deposit();
+    __syncthreads();
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int px0 = tx * PTW;
-        const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;                // conv pixel of tile-local (0, 0)
-        const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;                // input pixel of tile-local (0, 0)
-        if (tx > 0) __syncthreads();                                    // the pool of the previous tile is done with LDS
-        // ---- input tile: fp32 NHWC4 -> half, zeros outside the image (ZeroPadding2D(3))
-        for (int i = tid; i < IR * ICP; i += 256) {
-            const int r = i / ICP, c = i - r * ICP;
-            const int iy = iy0 + r, ix = ix0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f32x4 *>(img + ((long long)(b * H + iy) * W + ix) * 4);
-            *reinterpret_cast<f16x4 *>(tin + i * 4) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        }
-        __syncthreads();
+        const int cx0 = 2 * px0 - 1;
+        if (tx + 1 < tiles_x) fetch(tx + 1);                            // the next tile's pixels fly under this tile's MFMAs
 
-        // ---- conv: set s = conv pixels 32 s .. + 31 of the 9 x 33 region (row-major); waves take sets w, w + 4, ...
-        for (int s = wave; s < NSETS; s += 4) {
+        // ---- conv: set s = conv pixels 32 s .. + 31 of the 9 x 33 region (row-major)
+        for (int s = s0; s < NSETS; s += 2) {
             const int cp = min(s * 32 + p32, NCONV - 1);                // (the last set's spare lanes recompute pixel 296)
             const int cyl = cp / CC, cxl = cp - cyl * CC;
             const _Float16 *src = tin + ((2 * cyl) * ICP + 2 * cxl + 2 * q) * 4;      // kernel row 0, pixels 2 q, 2 q + 1
-            f32x16 acc[2];
+            f32x16 acc;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[nt][e] = bv[nt][e];
+            for (int e = 0; e < 16; ++e) acc[e] = bv[e];
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const f16x8 xv = *reinterpret_cast<const f16x8 *>(src + (ky * ICP + 4 * s2) * 4);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[0][ky * 2 + s2], xv, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[1][ky * 2 + s2], xv, acc[1], 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[ky * 2 + s2], xv, acc, 0, 0, 0);
                 }
             // ReLU, one rounding; conv pixels outside the conv map are the pool's zero padding
             const int cy = cy0 + cyl, cx = cx0 + cxl;
             const bool inside = (unsigned)cy < (unsigned)Hc && (unsigned)cx < (unsigned)Wc;
-            _Float16 *dst = tconv + (s * 32 + p32) * CPS;
+            _Float16 *dst = tconv + (s * 32 + p32) * CPS + nt * 32 + 4 * q;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int e4 = 0; e4 < 4; ++e4) {
+                f16x4 hv;
 #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    f16x4 hv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[e] = inside ? (_Float16)fmaxf(acc[nt][4 * e4 + e], 0.f) : (_Float16)0.f;
-                    *reinterpret_cast<f16x4 *>(dst + nt * 32 + 8 * e4 + 4 * q) = hv;
-                }
+                for (int e = 0; e < 4; ++e) hv[e] = inside ? (_Float16)fmaxf(acc[4 * e4 + e], 0.f) : (_Float16)0.f;
+                *reinterpret_cast<f16x4 *>(dst + 8 * e4) = hv;
+            }
         }
-        __syncthreads();
+        __syncthreads();                                                // conv tile complete; every wave is done reading `tin`
 
         // ---- 3 x 3 stride-2 max over the conv tile: 64 pooled pixels x 8 runs of 8 channels
         for (int i = tid; i < PTH * PTW * 8; i += 256) {
@@ -128,6 +150,8 @@ stem_pool_h_kernel(const float *__restrict__ img, const _Float16 *__restrict__ w
                 }
             *reinterpret_cast<f16x8 *>(out + ((long long)(b * Hp + oy) * Wp + ox) * 64 + cg * 8) = m;
         }
+        if (tx + 1 < tiles_x) deposit();                                // (`tin` is free since the barrier above)
+        __syncthreads();                                                // next input tile visible; pool done with `tconv`
     }
 }
 

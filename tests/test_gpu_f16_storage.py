@@ -173,7 +173,7 @@ def test_full_forward_half_storage_close_to_fp32_oracle(bt):
     got = model.predict(images)
     recs, ops.PROFILE = ops.PROFILE, None
     kernels = {r["kernel"] for r in recs}
-    assert {"conv1x1_pipe_h", "gconv3x3_mfma4_h", "maxpool3x3s2_h"} <= kernels, kernels   # the half path ran
+    assert {"conv1x1_pipe_h", "gconv3x3_mfma4_h", "stem7x7s2_pool_h"} <= kernels, kernels   # the half path ran
     want = O.inference_forward(cfg, w, images, literal_groups=False)
     worst = {}
     for name, g, r in zip(model.output_names, got, want):
