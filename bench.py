@@ -417,23 +417,24 @@ def cpu_baseline_and_parity(cfg, model, weights, hot_weights, backbone, batch, d
     # ---- the same forward with its convolutions on torch-CPU (oneDNN): what a competent CPU implementation costs.  The
     # patch lives in THIS leg only; the parity reference above came from the unpatched NumPy oracle.
     torch_tag = "torch-CPU convs"
+    # Thread counts: 16 (or every core of a smaller host), then 32 where the host has them, then 1.  NOT "all threads" on a
+    # big host: with 64 intra-op threads the many small convs of the towers thrash (round 4 box: 54 s per forward against
+    # 1.3 s with 16 threads) -- a data point that only costs minutes.
+    t_main = min(16, cores)
+    legs = [t_main] + ([] if quick else ([32] if cores >= 32 else []) + ([1] if t_main > 1 else []))
     with _TorchCpuConvs():
-        oracle_forward()                                         # warm-up (oneDNN primitive caches, weight re-layouts)
-        k_all = f"{full} {torch_tag}, all threads"
-        samples[k_all] = (_time_oracle(oracle_forward, 1, 0.0) if quick else _time_oracle(oracle_forward, 5, 30.0, 3))
-        threads_of[k_all] = cores
-        if not quick:
-            for nt in (16, 1):
-                if nt >= cores:
-                    continue
-                torch.set_num_threads(nt)
-                try:
-                    with threadpool_limits(limits=nt):
-                        k_nt = f"{full} {torch_tag}, {nt} thread{'s' if nt > 1 else ''}"
-                        samples[k_nt] = _time_oracle(oracle_forward, 3, 30.0, 2 if nt == 1 else 3)
-                        threads_of[k_nt] = nt
-                finally:
-                    torch.set_num_threads(cores)
+        for li, nt in enumerate(legs):
+            torch.set_num_threads(nt)
+            try:
+                with threadpool_limits(limits=nt):
+                    if li == 0:
+                        oracle_forward()                         # warm-up (oneDNN primitive caches, weight re-layouts)
+                    k_nt = f"{full} {torch_tag}, {nt} thread{'s' if nt > 1 else ''}"
+                    samples[k_nt] = (_time_oracle(oracle_forward, 1, 0.0) if quick else
+                                     _time_oracle(oracle_forward, 5 if li == 0 else 3, 25.0, 3 if li == 0 else 2))
+                    threads_of[k_nt] = nt
+            finally:
+                torch.set_num_threads(cores)
     best = min((k for k in samples if k.startswith(full)), key=lambda k: samples[k][0])
     dt, n_rep = samples[best]
     on_torch = torch_tag in best
