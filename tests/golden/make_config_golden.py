@@ -13,6 +13,10 @@ import importlib.util
 import json
 import os
 
+import sys
+
+sys.dont_write_bytecode = True      # /root/reference is read-only input: leave no __pycache__ beside the module loaded from it
+
 REF = "/root/reference/engine/config.py"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_defaults.json")
 

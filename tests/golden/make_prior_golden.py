@@ -14,6 +14,10 @@ import os
 
 import numpy as np
 
+import sys
+
+sys.dont_write_bytecode = True      # /root/reference is read-only input: leave no __pycache__ beside the module loaded from it
+
 REF = "/root/reference/engine/prior.py"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prior_tables.npz")
 
