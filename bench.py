@@ -79,7 +79,7 @@ WORKLOADS = {
     "resnext101_full_b16_1280_x3": ("resnext101", 16, 1280, 1280),   # configs[4] shape, fp32 tensors, f32x3
 }
 # which roofline binds each kernel class
-HBM_BOUND = ("groupnorm", "gconv3x3", "dwconv3x3", "maxpool", "stem7x7s2_pool", "resize", "preprocess", "detection", "cast", "trim",
+HBM_BOUND = ("groupnorm", "gconv3x3", "dwconv3x3", "maxpool", "stem7x7s2_pool_h", "resize", "preprocess", "detection", "cast", "trim",
              "semantic_smoothing", "crop_pad", "instance_summary")
 
 
@@ -147,7 +147,7 @@ _TRAFFIC_KERNELS = {
     "conv_mfma_128x64_x3": ("conv_mfma_kernel<4, 1, 1, 2, 3,",),
     "conv_mfma_128x128_h": ("conv_mfma_kernel<2, 2, 2, 2, 2,",),
     "conv1x1_h256_h": ("conv1x1_h256_kernel", "conv1x1_h8_kernel"), "conv1x1_pipe_h": ("conv1x1_pipe_kernel<_Float16",),
-    "conv1x1_pipe": ("conv1x1_pipe_kernel<float",), "gconv3x3_mfma4_h": ("gconv_mfma4h_kernel", "gconv16h_kernel"),
+    "conv1x1_pipe": ("conv1x1_pipe_kernel<float",), "conv1x1_pipe_x3": ("f32x3_t",), "gconv3x3_mfma4_h": ("gconv_mfma4h_kernel", "gconv16h_kernel"),
 }
 
 
@@ -681,7 +681,7 @@ def main():
                  "gbs": round(v["mbytes"] / max(v["ms"], 1e-9), 1)}
             if k.startswith(HBM_BOUND) or k.endswith("_h"):
                 e["bound"], e["hbm_frac"] = "hbm", round(e["gbs"] / PEAK_HBM_GBS, 4)
-            elif k.startswith(("conv_mfma", "conv1x1", "deconv2x2")):
+            elif k.startswith(("conv_mfma", "conv1x1", "deconv2x2", "stem7x7s2_pool")):     # (the fp32 fused stem is MFMA-bound)
                 # the dense MFMA peak of the type the kernel multiplies in: "_f16" / "_h" launches run fp16 MFMAs
                 peak = PEAK_F16_MFMA_TFLOPS if (k.endswith(("_f16", "_h")) or f16) else PEAK_F32_MFMA_TFLOPS
                 if k.endswith("_x3"):          # three f16 MFMA flops per algorithmic flop

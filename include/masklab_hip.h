@@ -48,7 +48,8 @@ enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
                                             mask-head tail descriptors, ml_mold_levels_f32
                                          6: ml_conv2d_launch_splits, ml_conv2d_gn_min_launch_tiles (reporting /
                                             the size rule of gn_partials asked of the library, not restated by callers)
-                                         7: ml_stem7x7s2_pool_f16; ml_gconv3x3_f16 takes groups of 32 channels        */
+                                         7: ml_stem7x7s2_pool_f16 / _f32; ml_gconv3x3_f16 takes groups of 32 channels;
+                                            ML_MATH_F32X3 on the persistent 1x1 kernel (ml_conv2d_uses_pipe)          */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -207,6 +208,12 @@ int ml_global_mean_f16(const void *in, void *out, int32_t B, int32_t HW, int32_t
  * one rounding: bit-identical to ml_conv2d_f32 (ML_MATH_F16, out_f16) followed by ml_maxpool3x3s2_f16, without the
  * un-pooled map (839 MB at 16 x 1280^2) ever reaching memory.                                                     */
 int ml_stem7x7s2_pool_f16(const float *image, const void *wgt_h, const float *bias, void *out, int32_t B, int32_t H,
+                          int32_t W, int32_t Hp, int32_t Wp, void *stream);
+/* The same stem on fp32 tensors with exact fp32 products (the default math): wgt = the fp32 row-span packing itself
+ * ([64][7 x 32]), out fp32 [B,Hp,Wp,64].  Only the products with a non-zero weight are issued (12 of the generic kernel's
+ * 16 MFMAs per kernel row), in the generic kernel's pairs and order: bit-identical to ml_conv2d_f32 (ML_MATH_F32, ReLU)
+ * followed by ml_maxpool3x3s2_f32, without the un-pooled map (537 MB at 8 x 1024^2) ever reaching memory.            */
+int ml_stem7x7s2_pool_f32(const float *image, const float *wgt, const float *bias, float *out, int32_t B, int32_t H,
                           int32_t W, int32_t Hp, int32_t Wp, void *stream);
 
 /* ---------------------------------------------------------------- fused mask-head tail

@@ -8,6 +8,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 void ml_set_error(const char *fmt, ...);
 
 #define ML_REQUIRE(cond, ...)                 \
@@ -32,6 +34,33 @@ __device__ __forceinline__ float ml_apply_act(float v, int act) {
     if (act == ML_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
     if (act == ML_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
     return v;
+}
+
+// ML_MATH_F32X3: 8 fp32 values -> 8 halves `hi` (round to nearest: v_cvt_pk_f16_f32) and 8 halves `lo` = (x - hi) * 2^11,
+// rounded to nearest.  x - hi is exact in fp32 (at most 13 significant bits), |lo| <= |x|, and the scaling keeps lo a NORMAL
+// half wherever x is one, so |x - (hi + 2^-11 lo)| <= 2^-22 |x| for 2^-14 <= |x| < 65520 (smaller: 2^-36; beyond: hi overflows, the result is
+// Inf / NaN -- loud, as in the fp16-storage mode).  16 VALU instructions: 4 packed multiplies (x * 2^11), 4 packed converts,
+// 8 v_fma_mix (f16 hi * -2^11 + the scaled x, result stored as f16).
+__device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, const float neg_scale, f16x8 &hi, f16x8 &lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x4 s0 = x0 * 2048.f, s1 = x1 * 2048.f;
+    unsigned hw[4], lw[4];
+    hw[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[0], x0[1]}, f16x2));
+    hw[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[2], x0[3]}, f16x2));
+    hw[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[0], x1[1]}, f16x2));
+    hw[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[2], x1[3]}, f16x2));
+    const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "+v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i + 1]));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 H = {hw[0], hw[1], hw[2], hw[3]}, L = {lw[0], lw[1], lw[2], lw[3]};
+    hi = __builtin_bit_cast(f16x8, H);
+    lo = __builtin_bit_cast(f16x8, L);
 }
 
 static inline bool ml_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -9,7 +9,12 @@
 //   _Float16  tensors (activations, residual, output, weights) fp16 in HBM, v_mfma_f32_32x32x16_f16 with fp32
 //             accumulation, bias / residual / clamp in fp32, ONE rounding to fp16 at the store: the "fp16 MFMA path"
 //             of BASELINE config 5 with fp16 STORAGE -- the 1x1 convs are HBM-bound there, so bytes are what counts.
-// A K chunk is 128 bytes per row for both (32 floats / 64 halves): staging, swizzle and fragment addressing are the
+//   f32x3_t   ML_MATH_F32X3: fp32 tensors like `float`, products on the f16 matrix pipe from split operands (three
+//             v_mfma_f32_32x32x16_f16 per 16-deep step, two accumulator sets; the weights arrive split, see x3_chunk).  The
+//             short-K 1x1 convs of ResNeXt stages 1-2 are HBM-bound in that mode: 24 MFMAs of 32 cycles per chunk against the
+//             64 x 64 cycles of `float`, so nothing needs to ride between MFMAs -- the epilogue of a tile runs in one piece at
+//             the start of the next tile's first chunk, behind that chunk's staging requests (round 4).
+// A K chunk is 128 bytes per row for all three (32 floats / 64 halves): staging, swizzle and fragment addressing are the
 // same code; a chunk is 64 MFMAs of 64 cycles (f32) or 16 MFMAs of 32 cycles (f16).
 //
 // What is different from the generic kernel
@@ -48,9 +53,10 @@ constexpr int SCRB = 16 * SCR_LD * 4;              // bytes of scratch per wave
 constexpr int pipe_lds_bytes(int nstage) { return nstage * BUFB + 4 * SCRB; }
 constexpr int PIPE_MAX_NBG = 8;                    // N tiles one block walks (its slice of the bias lives in LDS)
 
+struct f32x3_t { float v; };                       // storage type tag of ML_MATH_F32X3 (fp32 tensors, split-operand products)
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct PipeArgs {
     const void *in, *wgt, *res;
@@ -145,7 +151,7 @@ constexpr int RES_LEAD = 4;
 template <class T, int Q, bool HAS_RES, int NB4, bool CLAMP>
 __device__ __forceinline__ void finish_piece(const f32x16 (&acc)[2][2], const PipeState &S, char *scratch,
                                              __amdgpu_buffer_rsrc_t ro, const f32x4 (&bias)[2][NB4], f32x4 r0, f32x4 r1) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = !std::is_same<T, _Float16>::value;       // fp32 tensors (float, f32x3_t)
     constexpr int hs = Q & 1, qn = (Q >> 1) & 1, qm = Q >> 2;
     // C/D layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)) -> scratch[row][col]
     float *sw = reinterpret_cast<float *>(scratch + S.scr_w);
@@ -273,10 +279,115 @@ __device__ __forceinline__ void pipe_chunk(f32x16 (&cur)[2][2], f32x16 (&oth)[2]
     });
 }
 
+// ---- ML_MATH_F32X3 ------------------------------------------------------------------------------------------------------
+// Epilogue of one tile in one piece: the cross terms are folded in (units of 2^-11, as conv_mfma.hip does), ALL residual
+// pieces are requested at once (their 64 registers are the cross-term accumulators', dead after the fold), then the eight
+// pieces are transposed, finished and stored in order.  Vector-memory order: 16 residual loads, then 2 stores per piece --
+// younger than piece q's loads are the loads of pieces q+1 .. 7 and the stores of pieces 0 .. q-1: always 14.
+template <bool HAS_RES, bool CLAMP>
+__device__ __forceinline__ void x3_finish(f32x16 (&cur)[2][2], const f32x16 (&crx)[2][2], const PipeState &S, char *scratch,
+                                          __amdgpu_buffer_rsrc_t ro, const float *bias_lds, i32x4 rr) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cur[mi][ni][e] = fmaf(crx[mi][ni][e], 0x1p-11f, cur[mi][ni][e]);
+    __builtin_amdgcn_sched_barrier(0);                     // (the loads below take the registers the cross terms leave)
+    f32x4 ring[NPC][2];
+    static_for<0, NPC>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int hs = p & 1, pn = (p >> 1) & 1, pm = p >> 2;
+        if constexpr (HAS_RES) {
+            ring[p][0] = buf_load16_asm(rr, S.t_voff[pn], S.rowoff[(pm * 2 + hs) * 2 + 0]);
+            ring[p][1] = buf_load16_asm(rr, S.t_voff[pn], S.rowoff[(pm * 2 + hs) * 2 + 1]);
+        } else {
+            ring[p][0] = ring[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // the tile's bias comes from LDS here (bias_lds: this lane's four channels of N sub-tile 0; sub-tile 1 is 32 floats on):
+    // registers are what this form is short of at two blocks per CU
+    f32x4 bias[2][1];
+    bias[0][0] = *reinterpret_cast<const f32x4 *>(bias_lds);
+    bias[1][0] = *reinterpret_cast<const f32x4 *>(bias_lds + 32);
+    static_for<0, NPC>([&](auto pc) {
+        constexpr int q = decltype(pc)::value;
+        if constexpr (HAS_RES) wait_loaded<2 * (NPC - 1)>(ring[q][0], ring[q][1]);
+        finish_piece<float, q, HAS_RES, 1, CLAMP>(cur, S, scratch, ro, bias, ring[q][0], ring[q][1]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// One K chunk (32 deep) of the split-operand form.  Staged rows: activations 32 floats; weights 32 halves hi(w) then 32 halves
+// 2^11 (w - hi(w)) (masklab_hip.h, ML_MATH_F32X3) -- 128 bytes either way, so staging and swizzle are the `float` code.  Lane
+// (r, h) feeds k = 16 ks + 8 h .. + 7 of its row to v_mfma_f32_32x32x16_f16: eight floats (k-groups 4 ks + 2 h and + 1) split
+// here into hi / lo halves, weight k-groups 2 ks + h (hi) and 4 + 2 ks + h (lo).  Per 16-deep step and 32 x 32 sub-tile:
+// hi hi -> `cur`, hi lo and lo hi -> `crx` (same three products and the same k order as the generic kernel's X3 path).
+//   FIRST: the PREVIOUS tile, still in cur / crx, is finished and stored first (x3_finish) -- behind this chunk's staging
+//   requests, so those fly under it -- and the chains of the new tile start from zero.
+// Vector-memory order of a FIRST chunk, on which the caller's counted wait relies: 8 staging loads, 16 residual loads
+// (waited for inside), 16 stores.
+template <bool FIRST, bool HAS_RES, bool CLAMP>
+__device__ __forceinline__ void x3_chunk(f32x16 (&cur)[2][2], f32x16 (&crx)[2][2], const PipeState &S, const char *rd, char *wr,
+                                         char *scratch, __amdgpu_buffer_rsrc_t ra_nx, __amdgpu_buffer_rsrc_t rb_nx, int soff_nx,
+                                         __amdgpu_buffer_rsrc_t ro_prev, const float *bias_prev, i32x4 rr_prev) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(ra_nx, wr + (32 * i + 8 * S.wave_u) * ROWB, S.a_voff[i], soff_nx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(rb_nx, wr + (BM + 32 * i + 8 * S.wave_u) * ROWB, S.b_voff[i], soff_nx);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST) x3_finish<HAS_RES, CLAMP>(cur, crx, S, scratch, ro_prev, bias_prev, rr_prev);
+    const float neg_scale = -2048.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const char *row = rd + S.a_off + mi * 32 * ROWB;
+            split_hi_lo(*reinterpret_cast<const f32x4 *>(row + (((4 * ks + 2 * S.h) ^ S.swz) * 16)),
+                        *reinterpret_cast<const f32x4 *>(row + (((4 * ks + 2 * S.h + 1) ^ S.swz) * 16)), neg_scale, ah[mi], al[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const char *row = rd + S.b_off + ni * 32 * ROWB;
+            bh[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(row + (((2 * ks + S.h) ^ S.swz) * 16)));
+            bl[ni] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(row + (((4 + 2 * ks + S.h) ^ S.swz) * 16)));
+        }
+        if (FIRST && ks == 0) {                            // (compile time after unrolling) the chains start from C = 0
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) cur[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], zero, 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) crx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], zero, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) cur[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], cur[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) crx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], crx[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                crx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], crx[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // (keeps the second step's fragments out of the first step's registers)
+    }
+}
+
 template <class T, bool HAS_RES, int NSTAGE, bool CLAMP>
 __global__ void __launch_bounds__(256, NSTAGE == 2 ? 2 : 1)
 conv1x1_pipe_kernel(const PipeArgs A) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
+    constexpr bool F32 = !std::is_same<T, _Float16>::value;   // fp32 tensors
     constexpr int ES = sizeof(T);
     constexpr int KC = ROWB / ES;                              // K elements per chunk
     constexpr int NB4 = F32 ? 1 : 2;                           // float4 of bias per lane and N sub-tile
@@ -356,7 +467,10 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     float *lds_bias = reinterpret_cast<float *>(lds + NSTAGE * BUFB + 4 * SCRB);
     for (int i = tid; i < A.NBG * BN; i += 256) lds_bias[i] = A.bias ? A.bias[nt0 * BN + i] : 0.f;
     __syncthreads();
+    // X3: the address of this lane's bias slice of tile c (read in x3_finish); before the first tile: any valid slice
+    auto bias_at = [&](Cursor c) { return lds_bias + (c.u < A.panels ? c.nt - nt0 : 0) * BN + wn * 64 + t_col; };
     auto load_bias = [&](Cursor c, f32x4 (&bv)[2][NB4]) {
+        if constexpr (X3) return;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -395,6 +509,34 @@ conv1x1_pipe_kernel(const PipeArgs A) {
     int buf = 0;
     // One tile: `acc` accumulates it, `oth` holds the previous tile's result (finished and stored during the first
     // chunk).  Returns false after the block's last tile.
+    // X3: acc = the tile's hi x hi sums, crx = its cross terms; the first chunk (peeled: it stores the previous tile) and the rest
+    auto run_tile_x3 = [&](f32x16 (&acc)[2][2], f32x16 (&crx)[2][2]) -> bool {
+        const Cursor next = advance(cur);
+        const bool has_next = next.u < A.panels;
+        auto chunk = [&](auto firstc) __attribute__((always_inline)) {
+            constexpr bool first = decltype(firstc)::value;
+            const __amdgpu_buffer_rsrc_t ra_nx = res_a(nx), rb_nx = res_b(nx);
+            const int soff_nx = kc_nx * ROWB;
+            const char *rd = lds + buf * BUFB;
+            char *wr = lds + (buf == 0 ? NSTAGE - 1 : buf - 1) * BUFB;
+            if constexpr (first)
+                x3_chunk<true, HAS_RES, CLAMP>(acc, crx, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, res_o(prev), bias_at(prev), res_words(prev));
+            else
+                x3_chunk<false, HAS_RES, CLAMP>(acc, crx, S, rd, wr, scratch, ra_nx, rb_nx, soff_nx, ra_nx, nullptr, i32x4{0, 0, 0, 0});
+            ++kc_nx;
+            if (kc_nx == nk) { kc_nx = 0; nx = advance(nx); }
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+            // the next chunk has landed: younger than its requests are only the 16 stores of a first chunk (see run_tile)
+            if constexpr (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2) + 16) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NSTAGE - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        chunk(std::true_type{});
+        for (int kc = 1; kc < nk; ++kc) chunk(std::false_type{});
+        prev = cur;
+        cur = next;
+        return has_next;
+    };
     auto run_tile = [&](f32x16 (&acc)[2][2], f32x16 (&oth)[2][2]) -> bool {
         const Cursor next = advance(cur);
         const bool has_next = next.u < A.panels;
@@ -451,10 +593,16 @@ conv1x1_pipe_kernel(const PipeArgs A) {
             finish_piece<T, q, HAS_RES, NB4, CLAMP>(acc, S, scratch, ro, bias_prev, r0, r1);
         });
     };
-    // the tile loop, unrolled by two so that the accumulator sets swap roles without register copies
-    for (;;) {
-        if (!run_tile(accA, accB)) { drain(accA); break; }
-        if (!run_tile(accB, accA)) { drain(accB); break; }
+    if constexpr (X3) {
+        // accA / accB keep their roles (sums / cross terms); the last tile is finished by the same one-piece epilogue
+        while (run_tile_x3(accA, accB)) {}
+        x3_finish<HAS_RES, CLAMP>(accA, accB, S, scratch, res_o(prev), bias_at(prev), res_words(prev));
+    } else {
+        // the tile loop, unrolled by two so that the accumulator sets swap roles without register copies
+        for (;;) {
+            if (!run_tile(accA, accB)) { drain(accA); break; }
+            if (!run_tile(accB, accA)) { drain(accB); break; }
+        }
     }
 }
 
@@ -474,11 +622,11 @@ int launch_pipe(const PipeArgs &A, hipStream_t s) {
 
 // 1 when the problem is one this kernel handles (the caller otherwise uses the generic implicit-GEMM kernel)
 int ml_conv1x1_pipe_eligible(const ml_conv2d_desc &d) {
-    const bool f16s = d.math == ML_MATH_F16S;
+    const bool f16s = d.math == ML_MATH_F16S, x3 = d.math == ML_MATH_F32X3;
     const int kc = f16s ? 64 : 32;
     const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.dil == 1 && d.pad_t == 0 && d.pad_l == 0 &&
                           d.cpp_shift == 30 && d.group_cin_step == 0 && d.shuffle2x2 == 0 && d.out_bstride == 0 &&
-                          (d.math == ML_MATH_F32 || f16s) && d.Ho == d.H && d.Wo == d.W;
+                          (d.math == ML_MATH_F32 || f16s || x3) && d.Ho == d.H && d.Wo == d.W;
     if (!shape_ok || d.live || d.gn_partials) return 0;
     if (f16s && !d.out_f16) return 0;                     // this kernel stores the tensor type it reads (fp32 predictions: generic kernel)
     if (!f16s && d.out_f16) return 0;
@@ -549,6 +697,9 @@ int ml_conv1x1_pipe_try(const ml_conv2d_desc &d, hipStream_t s, int *eligible) {
     if (d.math == ML_MATH_F16S) {
         if (clamp) rc = d.residual ? launch_pipe<_Float16, true, 2, true>(A, s) : launch_pipe<_Float16, false, 2, true>(A, s);
         else rc = d.residual ? launch_pipe<_Float16, true, 2, false>(A, s) : launch_pipe<_Float16, false, 2, false>(A, s);
+    } else if (d.math == ML_MATH_F32X3) {        // d.wgt = the split packing (same bytes per row as fp32)
+        if (clamp) rc = d.residual ? launch_pipe<f32x3_t, true, 2, true>(A, s) : launch_pipe<f32x3_t, false, 2, true>(A, s);
+        else rc = d.residual ? launch_pipe<f32x3_t, true, 2, false>(A, s) : launch_pipe<f32x3_t, false, 2, false>(A, s);
     } else {
         if (clamp) rc = d.residual ? launch_pipe<float, true, 2, true>(A, s) : launch_pipe<float, false, 2, true>(A, s);
         else rc = d.residual ? launch_pipe<float, true, 2, false>(A, s) : launch_pipe<float, false, 2, false>(A, s);

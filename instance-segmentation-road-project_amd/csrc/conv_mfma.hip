@@ -146,11 +146,7 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
     return ok;
 }
 
-// ML_MATH_F32X3: 8 fp32 values -> 8 halves `hi` (round to nearest: v_cvt_pk_f16_f32) and 8 halves `lo` = (x - hi) * 2^11,
-// rounded to nearest.  x - hi is exact in fp32 (at most 13 significant bits), |lo| <= |x|, and the scaling keeps lo a NORMAL
-// half wherever x is one, so |x - (hi + 2^-11 lo)| <= 2^-22 |x| for 2^-14 <= |x| < 65520 (smaller: 2^-36; beyond: hi overflows, the result is
-// Inf / NaN -- loud, as in the fp16-storage mode).  16 VALU instructions: 4 packed multiplies (x * 2^11), 4 packed converts,
-// 8 v_fma_mix (f16 hi * -2^11 + the scaled x, result stored as f16).
+// (split_hi_lo: common.h)
 __device__ __forceinline__ void split_hi_lo_pair(const float xa, const float xb, const float neg_scale, unsigned &hi, unsigned &lo) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -161,27 +157,6 @@ __device__ __forceinline__ void split_hi_lo_pair(const float xa, const float xb,
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[1]));
 }
 
-__device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, const float neg_scale, f16x8 &hi, f16x8 &lo) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const f32x4 s0 = x0 * 2048.f, s1 = x1 * 2048.f;
-    unsigned hw[4], lw[4];
-    hw[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[0], x0[1]}, f16x2));
-    hw[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0[2], x0[3]}, f16x2));
-    hw[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[0], x1[1]}, f16x2));
-    hw[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x1[2], x1[3]}, f16x2));
-    const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-            : "+v"(lw[i]) : "v"(hw[i]), "s"(neg_scale), "v"(sv[2 * i + 1]));
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 H = {hw[0], hw[1], hw[2], hw[3]}, L = {lw[0], lw[1], lw[2], lw[3]};
-    hi = __builtin_bit_cast(f16x8, H);
-    lo = __builtin_bit_cast(f16x8, L);
-}
 
 // F16 = true: the "fp16 MFMA path" (BASELINE config 5): activations and weights stay fp32 in HBM, are
 // rounded to fp16 (RNE) on their way into LDS, and the contraction runs on v_mfma_f32_32x32x16_f16 with
@@ -1053,7 +1028,12 @@ int validate(const ml_conv2d_desc &d, bool generic = true) {
 // split-K: 64 panels of K = 2048 took 131 us against 50).  The rule looks at ONE image's pixel count, never at the
 // batch: an image's results must not depend on the shard it is computed in (tests/test_gpu_model.py).
 bool pipe_preferred(const ml_conv2d_desc &d) {
-    return d.KH == 1 && d.KW == 1 && d.span <= 512 && (long long)d.H * d.W >= 4096;
+    if (!(d.KH == 1 && d.KW == 1 && d.span <= 512 && (long long)d.H * d.W >= 4096)) return false;
+    // ML_MATH_F32X3 (round 4, gpurun_out/r04x_ab_x3*.txt): x1.3-1.4 where the launch is HBM-bound (K <= 256, or a residual
+    // to read: 5.2-5.5 TB/s against 3.4-3.9), x1.2 at 512 -> 1024 + residual; 512 -> 256 without one is compute-bound in
+    // that mode and 2-8 % faster on the generic 256-row tile
+    if (d.math == ML_MATH_F32X3) return d.span <= 256 || d.residual != nullptr;
+    return true;
 }
 
 // split-K heuristic: few tiles and a long K => slice K so that ~2 blocks per CU are in flight

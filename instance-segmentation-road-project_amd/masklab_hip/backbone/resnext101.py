@@ -159,7 +159,9 @@ class ResNeXt101(Layer):
         half = ops.half_storage()            # fp16-storage mode: the body's tensors AND its taps are IEEE half
         taps = {}
         if half and "C1" not in wanted and self.conv0.dev is not None:
-            x = ops.stem_pool_h(x, self.conv0.dev)        # stem + pool in one pass (csrc/stem_h.hip): fp16-storage mode only
+            x = ops.stem_pool_h(x, self.conv0.dev)        # stem + pool in one pass (csrc/stem_h.hip)
+        elif ops.CONV_MATH == "f32" and "C1" not in wanted and self.conv0.dev is not None:
+            x = ops.stem_pool(x, self.conv0.dev)          # exact-fp32 twin (csrc/stem_f32.hip): same bits as the pair below
         else:
             x = self.conv0(x, out_dtype=torch.float16 if half else None)
             taps["C1"] = x

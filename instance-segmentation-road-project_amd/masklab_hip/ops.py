@@ -331,7 +331,8 @@ def conv2d(x, dc: DeviceConv, stride=1, padding="same", dilation=1, act=_lib.ACT
     if PROFILE is not None:
         which = lib.ml_conv2d_uses_pipe(C.byref(d))          # 1: the 128 x 128 pipelined kernel, 2: the half 256 x 256 one
         if which:
-            name = "conv1x1_h256_h" if which == 2 else ("conv1x1_pipe_h" if x.dtype == torch.float16 else "conv1x1_pipe")
+            name = "conv1x1_h256_h" if which == 2 else (
+                "conv1x1_pipe_h" if x.dtype == torch.float16 else ("conv1x1_pipe_x3" if CONV_MATH == "f32x3" else "conv1x1_pipe"))
     _log_launch(C.byref(d), 1, ws, shape)
     with _Prof(name, flops, nbytes, shape) as prof:
         if prof.on and name == "conv1x1_h256_h":
@@ -481,6 +482,25 @@ def stem_pool_h(x4, dc: "DeviceConv"):
                f"B={B} HxW={H}x{W} -> {Hp}x{Wp}x64"):
         _lib.check(lib.ml_stem7x7s2_pool_f16(_ptr(x4), _ptr(wh), _ptr(dc.bias), _ptr(out), B, H, W, Hp, Wp, _stream()),
                    "ml_stem7x7s2_pool_f16")
+    return out
+
+
+def stem_pool(x4, dc: "DeviceConv"):
+    """ml_stem7x7s2_pool_f32: the fp32 twin of stem_pool_h -- exact fp32 products, only those with a non-zero weight, in the
+    generic kernel's order: the same bits as conv2d(stem, relu) + maxpool3x3s2 without the un-pooled map in memory."""
+    lib = _lib.load()
+    _require_dev(x4, "x4")
+    p = dc.p
+    B, H, W, c4 = x4.shape
+    if x4.dtype != torch.float32 or c4 != 4 or p.cpp_shift == 30 or p.KH != 7 or p.span_pad != 32 or p.cout != 64 or p.n_pad != 64:
+        raise ValueError("stem_pool: needs the fp32 NHWC4 image and the 7x7 / 64-filter row-span stem packing")
+    Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
+    out = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x4.device)
+    with _Prof("stem7x7s2_pool", 2.0 * B * Hc * Wc * 64 * 147, 16 * B * H * W + 4 * out.numel() + 4 * 64 * 224,
+               f"B={B} HxW={H}x{W} -> {Hp}x{Wp}x64"):
+        _lib.check(lib.ml_stem7x7s2_pool_f32(_ptr(x4), _ptr(dc.wgt), _ptr(dc.bias), _ptr(out), B, H, W, Hp, Wp, _stream()),
+                   "ml_stem7x7s2_pool_f32")
     return out
 
 

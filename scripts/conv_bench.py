@@ -31,10 +31,18 @@ SHAPES = [
 ]
 
 
-def ab_pipe(reps):
-    """generic kernel (tile 1) vs the pipelined 1x1 kernel (tile 4), interleaved rounds in one process."""
+def ab_pipe(reps, math="f32", big=False):
+    """generic kernel (tile 1) vs the pipelined 1x1 kernel (tile 4), interleaved rounds in one process.  --math f32x3: the
+    split-operand form of both (round 4); --big: the 16 x 1280^2 ResNeXt-101 shapes instead of 8 x 1024^2 ResNeXt-50."""
     rng = np.random.default_rng(0)
-    for label, B, H, W, cin, cout, k, stride, res in SHAPES:
+    ops.set_conv_math(math)
+    shapes = SHAPES
+    if big:
+        shapes = [("s1 64->128", 16, 320, 320, 64, 128, 1, 1, False), ("s1 64->256 sc", 16, 320, 320, 64, 256, 1, 1, False),
+                  ("s1 128->256 +res", 16, 320, 320, 128, 256, 1, 1, True), ("s1 256->128", 16, 320, 320, 256, 128, 1, 1, False),
+                  ("s2 256->512 +res", 16, 160, 160, 256, 512, 1, 1, True), ("s2 512->256", 16, 160, 160, 512, 256, 1, 1, False),
+                  ("s3 512->1024 +res", 16, 80, 80, 512, 1024, 1, 1, True), ("s3 1024->512", 16, 80, 80, 1024, 512, 1, 1, False)]
+    for label, B, H, W, cin, cout, k, stride, res in shapes:
         if k != 1 or stride != 1:
             continue
         x = torch.from_numpy(rng.normal(size=(B, H, W, cin)).astype(np.float32)).cuda()
@@ -57,8 +65,11 @@ def ab_pipe(reps):
         gf = 2.0 * out.numel() * cin / 1e9
         mb = 4 * (x.numel() + out.numel() * (2 if res else 1)) / 1e6
         m1, m4 = np.median(best[1]), np.median(best[4])
+        outs = [ops.conv2d(x, dcs[t], padding="same", act=_lib.ACT_RELU, residual=r) for t in (1, 4)]
+        diff = float((outs[0] - outs[1]).abs().max().item())
         print(f"{label:28s} generic {1e3 * m1:7.1f} us {gf / m1:6.1f} TF | pipe {1e3 * m4:7.1f} us {gf / m4:6.1f} TF "
-              f"{mb / m4:6.0f} GB/s | x{m1 / m4:.2f}", flush=True)
+              f"{mb / m4:6.0f} GB/s | x{m1 / m4:.2f} | max diff {diff:.3g}", flush=True)
+    ops.set_conv_math("f32")
 
 
 def half_pipe(reps):
@@ -129,13 +140,15 @@ def main():
     ap.add_argument("--lib", default=None, help="an experiment build of the library (the product path has no override)")
     ap.add_argument("--ab-pipe", action="store_true")
     ap.add_argument("--half-pipe", action="store_true")
+    ap.add_argument("--math", default="f32", choices=("f32", "f32x3"), help="conv math of --ab-pipe")
+    ap.add_argument("--big", action="store_true", help="--ab-pipe on the 16 x 1280^2 ResNeXt-101 shapes")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
     if args.half_heads:
         return half_heads(args.reps)
     if args.ab_pipe:
-        return ab_pipe(args.reps)
+        return ab_pipe(args.reps, args.math, args.big)
     if args.half_pipe:
         return half_pipe(args.reps)
     rng = np.random.default_rng(0)

@@ -213,25 +213,72 @@ def test_256_row_pipelined_tile(k, cin, cout, shape, res, dil, n_small):
 
 
 def test_short_k_residual_1x1_runs_on_128x64_tiles():
-    """The conv3 shapes of ResNeXt stages 1 / 2 (K <= 256, residual): HBM-bound, half a tile's time is its epilogue -- three
-    128 x 64 blocks per CU overlap epilogues and K loops.  Same values as any other tile shape; checked against the oracle."""
+    """The conv3 shapes of ResNeXt stages 1 / 2 (K <= 256, residual) on maps too small for the persistent kernel's rule (fewer
+    than 4 096 pixels per image): HBM-bound, half a tile's time is its epilogue -- three 128 x 64 blocks per CU overlap
+    epilogues and K loops.  Same values as any other tile shape; checked against the oracle."""
     from masklab_hip import _lib, ops, packing
     import ctypes as C
     rng = np.random.default_rng(12)
-    x = rng.normal(size=(2, 96, 96, 128)).astype(np.float32)
+    x = rng.normal(size=(8, 48, 48, 128)).astype(np.float32)
     w = (rng.normal(size=(1, 1, 128, 256)) / np.sqrt(128)).astype(np.float32)
     b = rng.normal(size=(256,)).astype(np.float32)
-    r = rng.normal(size=(2, 96, 96, 256)).astype(np.float32)
+    r = rng.normal(size=(8, 48, 48, 256)).astype(np.float32)
     dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
     xd, rd = dev(x), dev(r)
     d, _, _ = ops._conv_desc(xd, dc, 1, "valid", 1, _lib.ACT_RELU, rd)
     lib = _lib.load()
+    assert not lib.ml_conv2d_uses_pipe(C.byref(d))
     assert lib.ml_conv2d_launch_ntile(C.byref(d), 1, 1) == 64 and lib.ml_conv2d_launch_mtile(C.byref(d), 1, 1) == 128
     got = host(ops.conv2d(xd, dc, padding="valid", act=_lib.ACT_RELU, residual=rd))
     ref = T.relu(T.conv2d(x.astype(np.float64), w, b, 1, "valid") + r)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
     d2, _, _ = ops._conv_desc(xd, dc, 1, "valid", 1, _lib.ACT_RELU, None)            # no residual: the rule does not apply
     assert lib.ml_conv2d_launch_ntile(C.byref(d2), 1, 1) == 128
+
+
+@pytest.mark.parametrize("cin,cout,shape,res,act", [
+    (64, 256, (2, 96, 96), False, "relu"),      # two chunks, two N tiles of one group
+    (128, 256, (2, 96, 96), True, "relu"),      # the stage-1 conv3: residual, four chunks
+    (32, 128, (1, 64, 64), True, "none"),       # ONE chunk per tile: every chunk stores the previous tile
+    (256, 128, (3, 70, 67), False, "relu6"),    # ragged last panel (14 070 rows), clamp at 6
+    (512, 1024, (1, 64, 64), True, "relu"),     # eight N tiles: groups of tiles per block, 16 chunks
+])
+def test_short_k_1x1_on_the_persistent_kernel(cin, cout, shape, res, act):
+    """K <= 512 1x1 convs of maps with >= 4 096 pixels (ResNeXt stages 1-2 at the bench sizes) run the persistent pipelined
+    kernel with split-operand products (csrc/conv1x1_pipe.hip, f32x3_t): same three products per step and the same k order
+    as the generic kernel, bias and residual added after the sum instead of before (one rounding placed differently).
+    Against the fp64 oracle within the op tolerance, against the generic kernel (tile = 1) to 1e-5, and -- scheduling only --
+    one image alone equals the same image inside the batch bit for bit."""
+    from masklab_hip import _lib, ops, packing
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    B, H, W = shape
+    x = rng.normal(size=(B, H, W, cin)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    r = rng.normal(size=(B, H, W, cout)).astype(np.float32) if res else None
+    a = {"relu": _lib.ACT_RELU, "relu6": _lib.ACT_RELU6, "none": _lib.ACT_NONE}[act]
+    dc = ops.DeviceConv(packing.pack_dense(w, b), "cuda")
+    dc1 = ops.DeviceConv(packing.pack_dense(w, b, tile=1), "cuda")
+    xd, rd = dev(x), (None if r is None else dev(r))
+    d, _, _ = ops._conv_desc(xd, dc, 1, "valid", 1, a, rd)
+    assert _lib.load().ml_conv2d_uses_pipe(C.byref(d)) == 1
+    ops.PROFILE = []
+    got_d = ops.conv2d(xd, dc, padding="valid", act=a, residual=rd)
+    names, ops.PROFILE = [q["kernel"] for q in ops.PROFILE], None
+    assert names == ["conv1x1_pipe_x3"], names
+    got = host(got_d)
+    ref = T.conv2d(x.astype(np.float64), w, b, 1, "valid")
+    if res:
+        ref = ref + r
+    ref = {"relu": T.relu, "relu6": lambda v: np.clip(v, 0.0, 6.0), "none": lambda v: v}[act](ref)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    generic = host(ops.conv2d(xd, dc1, padding="valid", act=a, residual=rd))
+    np.testing.assert_allclose(got, generic, rtol=0, atol=1e-5)
+    one = host(ops.conv2d(dev(x[B - 1:]), dc, padding="valid", act=a, residual=None if r is None else dev(r[B - 1:])))
+    np.testing.assert_array_equal(one, got[B - 1:])
+    for _ in range(5):              # counted waits / cross-tile requests: repeated launches give the same bits
+        np.testing.assert_array_equal(host(ops.conv2d(xd, dc, padding="valid", act=a, residual=rd)), got)
 
 
 def test_groupnorm_partials_from_the_256_row_tile():

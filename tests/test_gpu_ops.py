@@ -216,6 +216,30 @@ def test_conv2d_rowspan_stem(k, stride, padding, cout, act, conv_math):
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 41), (3, 130, 70), (1, 256, 512)])
+def test_fused_fp32_stem_and_pool_equals_the_two_kernels(B, H, W):
+    """csrc/stem_f32.hip (round 4): ZeroPadding2D(3) + 7x7 stride-2 conv + folded BN + ReLU + ZeroPadding2D(1) + 3x3 stride-2
+    max-pool in ONE kernel with exact fp32 products (reference engine/backbone/ResNext.py:343-352).  Only the products with a
+    non-zero weight are issued, in the generic kernel's pairs and order, from the bias: BIT-identical to conv2d + maxpool3x3s2,
+    and the oracle's values within the conv tolerance.  Odd sizes exercise the zero padding on every side and partial
+    pooled tiles; an image with negative-only channels checks that the pool's zero padding never beats a real value wrongly."""
+    from masklab_hip import _lib, ops, packing
+    x = rnd(B, H, W, 3)
+    x[0, :, : W // 3] -= 3.0                                   # a region where most conv outputs are cut by the ReLU
+    x4 = np.concatenate([x, np.zeros_like(x[..., :1])], -1)
+    w, b = rnd(7, 7, 3, 64, scale=0.08), rnd(64)
+    dc = ops.DeviceConv(packing.pack_rowspan(w, b), "cuda")
+    two = ops.maxpool3x3s2(ops.conv2d(dev(x4), dc, stride=2, padding=((3, 3), (3, 3)), act=_lib.ACT_RELU), pad=1)
+    one = ops.stem_pool(dev(x4), dc)
+    assert one.dtype == torch.float32 and one.shape == two.shape
+    np.testing.assert_array_equal(host(one), host(two))
+    conv = T.relu(T.conv2d(x.astype(np.float64), w, b, 2, ((3, 3), (3, 3))))
+    ref = T.max_pool(np.pad(conv, ((0, 0), (1, 1), (1, 1), (0, 0))), 3, 2)
+    np.testing.assert_allclose(host(one), ref, rtol=0, atol=2e-5)
+    with pytest.raises(ValueError):
+        ops.stem_pool(dev(x4), ops.DeviceConv(packing.pack_dense(rnd(3, 3, 4, 64), b), "cuda"))
+
+
 @pytest.mark.parametrize("c,stride,filters", [(4, 1, 128), (8, 2, 256), (16, 1, 512), (32, 2, 1024)])
 def test_conv2d_grouped_resnext(c, stride, filters, conv_math):
     from masklab_hip import _lib, packing
