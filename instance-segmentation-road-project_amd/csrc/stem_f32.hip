@@ -18,28 +18,36 @@
 //     floats; 32 lanes read conv pixels 24 bytes apart: no bank conflict);
 //   * a block walks a ROW of pooled tiles with its 84 weight registers resident, the next tile's image pixels fetched into
 //     registers under the current tile's MFMAs; wave w multiplies output channels 32 (w >> 1) .. + 31 by every other set of
-//     32 conv pixels, two sets at a time (two independent accumulator chains keep the matrix pipe issuing back to back).
-// MFMA-bound: 10 sets x 2 x 84 MFMAs of 64 cycles per tile = 0.36 ms at 8 x 1024^2 on 1 024 SIMDs; HBM traffic 100 MB in +
-// 134 MB out.
+//     32 conv pixels, two sets at a time (two independent accumulator chains).
+// Measured at 8 x 1024^2: 507 us against 545 + 143 for the two launches -- 71 % of the MFMA time of the chains it issues
+// (8 192 tiles x 20 x 84 MFMAs of 64 cycles = 0.36 ms on 1 024 SIMDs), the same fraction the generic kernel reaches on this
+// K = 7-chunk problem; pool, deposit and the two barriers per tile are not covered by matrix work with one block per CU.
+// Measured and not kept: eight waves (two per SIMD, 5 x 16 pooled tile, one chain per wave, runs of two tiles per block):
+// 548 us; the B operands read from LDS one kernel row ahead of their MFMAs (pinned with sched_barrier): 524 us -- the LDS
+// latency is not what the chains wait for; runs of two tiles per block instead of whole rows: 582 us (the prologue).
+// HBM traffic 100 MB in + 134 MB out.
 #include <type_traits>
 #include "common.h"
 
 namespace {
 
 constexpr int PTH = 4, PTW = 16;                  // pooled tile
+constexpr int NT = 256;                           // threads: 4 waves, one per SIMD
 constexpr int CR = 2 * PTH + 1, CC = 2 * PTW + 1; // conv pixels it needs: 9 x 33
 constexpr int IR = 2 * (CR - 1) + 7;              // input rows: 23
 constexpr int ICP = 2 * (CC - 1) + 8;             // input pixels per row: 72 (71 used + the zero-weight 8th tap pixel)
 constexpr int NCONV = CR * CC;                    // 297
-constexpr int NSETS = (NCONV + 31) / 32;          // 10 sets of 32 conv pixels
+constexpr int NSETS = (NCONV + 31) / 32;          // 10 sets of 32 conv pixels: 5 per wave
 constexpr int CPS = 68;                           // floats per conv pixel in LDS (64 + 4 pad: 272 B)
 constexpr int IN_BYTES = IR * ICP * 3 * 4;        // 19 872: the input tile as 3-channel pixels
 constexpr int CONV_BYTES = NSETS * 32 * CPS * 4;  // 87 040
 constexpr int STEM_LDS = IN_BYTES + CONV_BYTES;   // 106 912: one block per CU
 
-__global__ void __launch_bounds__(256, 1)
+static_assert(NSETS == 10, "the wave -> set map below assumes 10 sets");
+
+__global__ void __launch_bounds__(NT, 1)
 stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wgt, const float *__restrict__ bias,
-                     float *__restrict__ out, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_x) {
+                     float *__restrict__ out, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_x, int seg) {
     extern __shared__ __align__(16) char lds[];
     float *tin = reinterpret_cast<float *>(lds);                        // [IR][ICP][3]
     float *tconv = reinterpret_cast<float *>(lds + IN_BYTES);           // [NSETS * 32][CPS]
@@ -50,7 +58,7 @@ stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wg
     const int py0 = ty * PTH;
     const int cy0 = 2 * py0 - 1;                                        // conv row of tile-local row 0
     const int iy0 = 2 * cy0 - 3;                                        // input row of tile-local row 0
-    const int nt = wave >> 1, s0 = wave & 1;
+    const int nt = wave >> 1, s0 = wave & 1;                            // sets s0, s0 + 2, .. + 8 against channels 32 nt ..
 
     // weights: A operand of MFMA (ky, ks, j) = W[output channel 32 nt + p32][kernel row ky][pixel 2 ks + q][channel j], straight
     // from the generic kernel's row-span packing ([64][7 x 32]: 8 pixels x 4 channels per kernel row)
@@ -67,12 +75,12 @@ stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wg
     for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * q] : 0.f;
 
     // ---- this thread's share of an input tile: pixels tid + 256 j of the [IR][ICP] grid (fp32 NHWC4 -> 3 floats in LDS)
-    constexpr int NIN = (IR * ICP + 255) / 256;                         // 7
+    constexpr int NIN = (IR * ICP + NT - 1) / NT;                       // 7
     int in_c[NIN];
     long long in_off[NIN];                                              // float offset of (row, column 0 of the image), -1: zeros
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + NT * j;
         const int in_r = i / ICP;
         in_c[j] = i - in_r * ICP;
         const int iy = iy0 + in_r;
@@ -93,7 +101,7 @@ stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wg
     auto deposit = [&]() __attribute__((always_inline)) {              // registers -> LDS
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NT * j;
             if (i < IR * ICP) {
                 tin[i * 3 + 0] = stage[j][0];
                 tin[i * 3 + 1] = stage[j][1];
@@ -142,22 +150,24 @@ stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wg
         }
     };
 
-    fetch(0);
+    // this block's run of pooled tiles in its row: seg of them (the launcher cuts rows so that blocks are many and short)
+    const int tx_begin = blockIdx.z * seg, tx_end = min(tiles_x, tx_begin + seg);
+    fetch(tx_begin);
     deposit();
     __syncthreads();
-    for (int tx = 0; tx < tiles_x; ++tx) {
+    for (int tx = tx_begin; tx < tx_end; ++tx) {
         const int px0 = tx * PTW;
         const int cx0 = 2 * px0 - 1;
-        if (tx + 1 < tiles_x) fetch(tx + 1);                            // the next tile's pixels fly under this tile's MFMAs
+        if (tx + 1 < tx_end) fetch(tx + 1);                             // the next tile's pixels fly under this tile's MFMAs
 
-        // ---- conv: set s = conv pixels 32 s .. + 31 of the 9 x 33 region (row-major); this wave: s0, s0 + 2, ... (5 sets)
+        // ---- conv: set s = conv pixels 32 s .. + 31 of the 9 x 33 region (row-major); this wave: s0, s0 + 2, ... (5 sets, two at a time)
         conv_sets(std::integral_constant<int, 2>{}, s0, cx0);
         conv_sets(std::integral_constant<int, 2>{}, s0 + 4, cx0);
         conv_sets(std::integral_constant<int, 1>{}, s0 + 8, cx0);
         __syncthreads();                                                // conv tile complete; every wave is done reading `tin`
 
         // ---- 3 x 3 stride-2 max over the conv tile: 64 pooled pixels x 16 runs of 4 channels
-        for (int i = tid; i < PTH * PTW * 16; i += 256) {
+        for (int i = tid; i < PTH * PTW * 16; i += NT) {
             const int cg = i & 15, pp = i >> 4;
             const int ppy = pp / PTW, ppx = pp - ppy * PTW;
             const int oy = py0 + ppy, ox = px0 + ppx;
@@ -174,7 +184,7 @@ stem_pool_f32_kernel(const float *__restrict__ img, const float *__restrict__ wg
                 }
             *reinterpret_cast<f32x4 *>(out + ((long long)(b * Hp + oy) * Wp + ox) * 64 + cg * 4) = m;
         }
-        if (tx + 1 < tiles_x) deposit();                                // (`tin` is free since the barrier above)
+        if (tx + 1 < tx_end) deposit();                                 // (`tin` is free since the barrier above)
         __syncthreads();                                                // next input tile visible; pool done with `tconv`
     }
 }
@@ -194,8 +204,13 @@ extern "C" int ml_stem7x7s2_pool_f32(const float *image, const float *wgt, const
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(stem_pool_f32_kernel), STEM_LDS, lds_ok, "stem7x7s2_pool_f32")) return rc;
     const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
-    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(tiles_y, B), dim3(256), STEM_LDS, (hipStream_t)stream, image, wgt, bias, out, H, W,
-                       Hc, Wc, Hp, Wp, tiles_x);
+    // a block keeps its weights in registers over `seg` tiles of a row: whole rows when that gives two blocks per CU or more
+    // (its prologue -- 84 strided weight loads per lane -- wants many tiles behind it: runs of 2 tiles measured 582 us against
+    // 507 for whole rows at 8 x 1024^2), shorter runs only for launches that would otherwise leave CUs empty
+    int seg = tiles_x;
+    while (seg > 1 && (long long)tiles_y * B * ((tiles_x + seg - 1) / seg) < 2ll * ml_resident_blocks(1)) seg = (seg + 1) / 2;
+    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(tiles_y, B, (tiles_x + seg - 1) / seg), dim3(NT), STEM_LDS, (hipStream_t)stream,
+                       image, wgt, bias, out, H, W, Hc, Wc, Hp, Wp, tiles_x, seg);
     ML_CHECK_LAUNCH("stem7x7s2_pool_f32");
     return ML_OK;
 }
