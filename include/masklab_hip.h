@@ -48,7 +48,7 @@ enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
                                             mask-head tail descriptors, ml_mold_levels_f32
                                          6: ml_conv2d_launch_splits, ml_conv2d_gn_min_launch_tiles (reporting /
                                             the size rule of gn_partials asked of the library, not restated by callers)
-                                         7: ml_stem7x7s2_pool_f16 / _f32; ml_gconv3x3_f16 takes groups of 32 channels;
+                                         7: ml_stem7x7s2_pool_f16 / _f32 / _x3; ml_gconv3x3_f16 takes groups of 32 channels;
                                             ML_MATH_F32X3 on the persistent 1x1 kernel (ml_conv2d_uses_pipe)          */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
@@ -215,6 +215,11 @@ int ml_stem7x7s2_pool_f16(const float *image, const void *wgt_h, const float *bi
  * followed by ml_maxpool3x3s2_f32, without the un-pooled map (537 MB at 8 x 1024^2) ever reaching memory.            */
 int ml_stem7x7s2_pool_f32(const float *image, const float *wgt, const float *bias, float *out, int32_t B, int32_t H,
                           int32_t W, int32_t Hp, int32_t Wp, void *stream);
+/* ... and with ML_MATH_F32X3 products: wgt_x3 = the split row-span packing (per kernel row 32 hi halves, then 32 halves
+ * 2^11 (w - hi)); the image values are split once, on their way into LDS.  Same steps, products and order as the generic
+ * kernel's X3 path: bit-identical to ml_conv2d_f32 (ML_MATH_F32X3, ReLU) followed by ml_maxpool3x3s2_f32.            */
+int ml_stem7x7s2_pool_x3(const float *image, const void *wgt_x3, const float *bias, float *out, int32_t B, int32_t H,
+                         int32_t W, int32_t Hp, int32_t Wp, void *stream);
 
 /* ---------------------------------------------------------------- fused mask-head tail
  * Conv2DTranspose(C_mid, (2,2), (2,2)) + bias + act_mid followed by Conv2D(ncls, (1,1)) + bias + act_out in one

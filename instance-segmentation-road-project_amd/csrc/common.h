@@ -63,6 +63,17 @@ __device__ __forceinline__ void split_hi_lo(const f32x4 x0, const f32x4 x1, cons
     lo = __builtin_bit_cast(f16x8, L);
 }
 
+// the same split for two values (packed halves in one register each)
+__device__ __forceinline__ void split_hi_lo_pair(const float xa, const float xb, const float neg_scale, unsigned &hi, unsigned &lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {xa, xb};
+    const f32x2 sc = x * 2048.f;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[1]));
+}
+
 static inline bool ml_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: `done` (one per kernel) remembers

@@ -146,16 +146,7 @@ __device__ __forceinline__ bool out_vec_ok(const ml_conv2d_desc &p) {
     return ok;
 }
 
-// (split_hi_lo: common.h)
-__device__ __forceinline__ void split_hi_lo_pair(const float xa, const float xb, const float neg_scale, unsigned &hi, unsigned &lo) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const f32x2 x = {xa, xb};
-    const f32x2 sc = x * 2048.f;
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc[1]));
-}
+// (split_hi_lo, split_hi_lo_pair: common.h)
 
 
 // F16 = true: the "fp16 MFMA path" (BASELINE config 5): activations and weights stay fp32 in HBM, are

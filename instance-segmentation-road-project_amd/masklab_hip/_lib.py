@@ -81,6 +81,7 @@ SIGNATURES = {
     "ml_maxpool3x3s2_f16": (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "ml_stem7x7s2_pool_f16": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
     "ml_stem7x7s2_pool_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
+    "ml_stem7x7s2_pool_x3": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
     "ml_subsample2_f16": (C.c_int, [_vp, _vp] + [_i32] * 4 + [_vp]),
     "ml_cast_f16_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_cast_f32_to_f16": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -90,8 +90,8 @@ class ResNeXt50(Layer):
         if half and "C1" not in wanted and self.conv1.dev is not None:
             # fp16-storage mode and nobody asked for the un-pooled stem output: stem + pool in one pass (csrc/stem_h.hip)
             x = ops.stem_pool_h(x, self.conv1.dev)
-        elif ops.CONV_MATH == "f32" and "C1" not in wanted and self.conv1.dev is not None:
-            x = ops.stem_pool(x, self.conv1.dev)               # exact-fp32 twin (csrc/stem_f32.hip): same bits as the pair below
+        elif ops.CONV_MATH in ("f32", "f32x3") and "C1" not in wanted and self.conv1.dev is not None:
+            x = ops.stem_pool(x, self.conv1.dev)               # fp32-tensor twins (csrc/stem_f32.hip, stem_x3.hip): same bits as the pair below
         else:
             x = self.conv1(x, out_dtype=torch.float16 if half else None)
             taps["C1"] = x

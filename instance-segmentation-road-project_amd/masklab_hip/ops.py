@@ -486,21 +486,25 @@ def stem_pool_h(x4, dc: "DeviceConv"):
 
 
 def stem_pool(x4, dc: "DeviceConv"):
-    """ml_stem7x7s2_pool_f32: the fp32 twin of stem_pool_h -- exact fp32 products, only those with a non-zero weight, in the
-    generic kernel's order: the same bits as conv2d(stem, relu) + maxpool3x3s2 without the un-pooled map in memory."""
+    """ml_stem7x7s2_pool_f32 / _x3: the fp32-tensor twins of stem_pool_h, in the current conv math ("f32": exact fp32
+    products, only those with a non-zero weight; "f32x3": the split-operand products) -- the same bits as
+    conv2d(stem, relu) + maxpool3x3s2 in that math, without the un-pooled map in memory."""
     lib = _lib.load()
     _require_dev(x4, "x4")
     p = dc.p
     B, H, W, c4 = x4.shape
     if x4.dtype != torch.float32 or c4 != 4 or p.cpp_shift == 30 or p.KH != 7 or p.span_pad != 32 or p.cout != 64 or p.n_pad != 64:
         raise ValueError("stem_pool: needs the fp32 NHWC4 image and the 7x7 / 64-filter row-span stem packing")
+    if CONV_MATH not in ("f32", "f32x3"):
+        raise ValueError(f"stem_pool: no fused stem in conv math {CONV_MATH!r}")
+    x3 = CONV_MATH == "f32x3"
     Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     Hp, Wp = (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
     out = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x4.device)
-    with _Prof("stem7x7s2_pool", 2.0 * B * Hc * Wc * 64 * 147, 16 * B * H * W + 4 * out.numel() + 4 * 64 * 224,
-               f"B={B} HxW={H}x{W} -> {Hp}x{Wp}x64"):
-        _lib.check(lib.ml_stem7x7s2_pool_f32(_ptr(x4), _ptr(dc.wgt), _ptr(dc.bias), _ptr(out), B, H, W, Hp, Wp, _stream()),
-                   "ml_stem7x7s2_pool_f32")
+    with _Prof("stem7x7s2_pool_x3" if x3 else "stem7x7s2_pool", 2.0 * B * Hc * Wc * 64 * 147,
+               16 * B * H * W + 4 * out.numel() + 4 * 64 * 224, f"B={B} HxW={H}x{W} -> {Hp}x{Wp}x64"):
+        fn, w = (lib.ml_stem7x7s2_pool_x3, dc.wgt_x3) if x3 else (lib.ml_stem7x7s2_pool_f32, dc.wgt)
+        _lib.check(fn(_ptr(x4), _ptr(w), _ptr(dc.bias), _ptr(out), B, H, W, Hp, Wp, _stream()), "ml_stem7x7s2_pool")
     return out
 
 

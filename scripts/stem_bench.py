@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The fp32 ResNeXt stem: fused conv 7x7 s2 + ReLU + max-pool (csrc/stem_f32.hip) against the two launches it replaces.
+"""The fp32-tensor ResNeXt stem: fused conv 7x7 s2 + ReLU + max-pool (csrc/stem_f32.hip; --math f32x3: stem_x3.hip) against the
+two launches it replaces.
 Usage (GPU box): python scripts/stem_bench.py [--lib experiment.so] [--reps 20]"""
 import argparse
 import os
@@ -15,10 +16,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=None, help="an experiment build of the library (the product path has no override)")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--math", default="f32", choices=("f32", "f32x3"))
     args = ap.parse_args()
     from masklab_hip import _lib, ops, packing
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
+    ops.set_conv_math(args.math)
     rng = np.random.default_rng(0)
     w = (rng.normal(size=(7, 7, 3, 64)) * 0.08).astype(np.float32)
     b = rng.normal(size=(64,)).astype(np.float32)

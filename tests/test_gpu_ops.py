@@ -217,12 +217,13 @@ def test_conv2d_rowspan_stem(k, stride, padding, cout, act, conv_math):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 41), (3, 130, 70), (1, 256, 512)])
-def test_fused_fp32_stem_and_pool_equals_the_two_kernels(B, H, W):
-    """csrc/stem_f32.hip (round 4): ZeroPadding2D(3) + 7x7 stride-2 conv + folded BN + ReLU + ZeroPadding2D(1) + 3x3 stride-2
-    max-pool in ONE kernel with exact fp32 products (reference engine/backbone/ResNext.py:343-352).  Only the products with a
-    non-zero weight are issued, in the generic kernel's pairs and order, from the bias: BIT-identical to conv2d + maxpool3x3s2,
-    and the oracle's values within the conv tolerance.  Odd sizes exercise the zero padding on every side and partial
-    pooled tiles; an image with negative-only channels checks that the pool's zero padding never beats a real value wrongly."""
+def test_fused_fp32_stem_and_pool_equals_the_two_kernels(B, H, W, conv_math):
+    """csrc/stem_f32.hip, stem_x3.hip (round 4): ZeroPadding2D(3) + 7x7 stride-2 conv + folded BN + ReLU + ZeroPadding2D(1) +
+    3x3 stride-2 max-pool in ONE kernel on fp32 tensors (reference engine/backbone/ResNext.py:343-352).  "f32": exact fp32
+    products, only those with a non-zero weight, in the generic kernel's pairs and order, from the bias; "f32x3": the generic
+    kernel's split-operand steps.  Either way BIT-identical to conv2d + maxpool3x3s2 in that math, and the oracle's values
+    within the conv tolerance.  Odd sizes exercise the zero padding on every side and partial pooled tiles; a region of
+    mostly negative conv outputs checks the ReLU / zero-padding interplay of the pool."""
     from masklab_hip import _lib, ops, packing
     x = rnd(B, H, W, 3)
     x[0, :, : W // 3] -= 3.0                                   # a region where most conv outputs are cut by the ReLU
