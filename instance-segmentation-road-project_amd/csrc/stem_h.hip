@@ -4,9 +4,8 @@
 //
 // Why fused, and only on this path: at 16 x 1280^2 the stem's output is 839 MB of half written and read back by the pool
 // (0.78 + 0.23 ms of the fp16 step) while the conv itself is ~90 us of fp16 MFMA -- recomputing the pool's one-pixel halo
-// (9 x 33 conv pixels for a 4 x 16 pooled tile: +16 %) costs nothing beside the bytes it saves.  In fp32 the stem is MFMA-bound
-//  and stays unfused; a caller that asks for the C1 tap (the un-pooled stem output) gets
-// the unfused pair too.
+// (9 x 33 conv pixels for a 4 x 16 pooled tile: +16 %) costs nothing beside the bytes it saves.  (fp32 tensors: stem_f32.hip /
+// stem_x3.hip.)  A caller that asks for the C1 tap (the un-pooled stem output) gets the unfused pair.
 //
 //   * K order = (kernel row, 8 pixels x 4 channels) exactly as the generic kernel's row-span packing: 7 rows x 32, the 8th
 //     pixel and the 4th channel carry zero weights; a 16-deep MFMA step is half a kernel row, lane half h two of its pixels
