@@ -64,7 +64,7 @@ template <int STRIDE, int TH, int TW, int CPG, class TIO>
 __global__ void __launch_bounds__(256)
 gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
                    TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
-                   int tiles_x) {
+                   int tiles_x, int tiles_y, int seg) {
     constexpr int c = CPG;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
@@ -79,90 +79,105 @@ gconv_mfma4_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, co
     static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
     extern __shared__ __align__(16) float tile[];   // [NPIX][PS]
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // A block walks a run of `seg` tiles DOWN one tile column of its image and 64-channel slab (round 4): its weights are
+    // read once, and the next tile's halo is fetched into registers while the current one is multiplied -- a one-tile
+    // block spent its life in the chain load -> LDS -> compute -> store with only the co-resident blocks to cover it, and
+    // re-read 9 c x 64 weights (as many bytes as the tile itself at c = 16) from L2 for every tile.  Per launch
+    // (profiles/r04_gconv_walker_ab.txt): fp32 c = 4 143 -> 124 us, c = 8 stride 2 177 -> 149; half c = 8 179 -> 127, c = 4
+    // 219 -> 196; the c = 16 forms +-3 %.  (The first form kept every halo pixel's coordinates and address in registers
+    // across the MFMA loop -- 76 -> 150 VGPRs, half the blocks per CU, fp32 c = 4 SLOWER than one-tile blocks; `fetch`
+    // now recomputes them per tile from an opaque copy of the thread index.)
+    const int tx = blockIdx.x % tiles_x, sg = blockIdx.x / tiles_x;
+    const int ty_begin = sg * seg, ty_end = min(tiles_y, ty_begin + seg);
     const int cs0 = blockIdx.y * CS;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int ox0 = tx * TW;
+    const int ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = lane >> 2;            // 0..15: 4 output channels cs0 + 4*blk + (0..3)
     const int sub = lane & 3;             // A: output channel within the block; B/D: pixel within the quad
 
-    // ---- all global loads of the block are issued up front (memory-level parallelism): the halo
-    //      tile (16 float4 per pixel, zero outside the image) and this lane's 9*c weights
+    // ---- the halo tile of a tile row (16-byte pieces, zero outside the image) goes to registers first
     typename Stage16<TIO>::type stage[NLD];
-    {
-        const int cN = (tid % TPP) * CPT;
+    const int cN = (tid % TPP) * CPT;
+    auto fetch = [&](int ty) __attribute__((always_inline)) {
+        const int iy0 = ty * TH * STRIDE - pad_t;
+        int tl = tid;                                     // (opaque copy: the pixel coordinates below are recomputed per tile
+        asm volatile("" : "+v"(tl));                     //  instead of living in ~30 registers across the MFMA loop)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = tid / TPP + PPP * i;
+            const int p = tl / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
             typename Stage16<TIO>::type v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + (tl % TPP) * CPT);
             stage[i] = v;
         }
-    }
+    };
+    fetch(ty_begin);
     f32x4 wv[WV];
     {
         const float *wrow = wgt + (long long)(cs0 + blk * 4 + sub) * 9 * c;
 #pragma unroll
         for (int i = 0; i < WV; ++i) wv[i] = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
     }
-    {
-        const int cN = (tid % TPP) * CPT;
+    const int gch = ((cs0 + blk * 4) / c) * c - cs0;      // first input channel of the block's group, slab-relative
+    int qbase[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int quad = wave * QPW + q;
+        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
+        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PS + gch;
+    }
+    const int oc = cs0 + blk * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        if (ty > ty_begin) __syncthreads();               // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid / TPP + PPP * i;
             if (p < NPIX) stage_to_lds<TIO>(tile + p * PS + cN, stage[i]);
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        if (ty + 1 < ty_end) fetch(ty + 1);               // flies under this tile's MFMAs
 
-    const int gch = ((cs0 + blk * 4) / c) * c - cs0;      // first input channel of the block's group, slab-relative
-    f32x4 acc[QPW];
-    int qbase[QPW];
+        f32x4 acc[QPW];
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
-        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int quad = wave * QPW + q;
-        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
-        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PS + gch;
-    }
-
+        for (int q = 0; q < QPW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * TWIN + (t % 3)) * PS;
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * TWIN + (t % 3)) * PS;
 #pragma unroll
-        for (int i0 = 0; i0 < c; i0 += 4) {
-            const f32x4 w4 = wv[(t * c + i0) / 4];
-            f32x4 xv[QPW];
+            for (int i0 = 0; i0 < c; i0 += 4) {
+                const f32x4 w4 = wv[(t * c + i0) / 4];
+                f32x4 xv[QPW];
 #pragma unroll
-            for (int q = 0; q < QPW; ++q) xv[q] = *reinterpret_cast<const f32x4 *>(tile + qbase[q] + toff + i0);
+                for (int q = 0; q < QPW; ++q) xv[q] = *reinterpret_cast<const f32x4 *>(tile + qbase[q] + toff + i0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < QPW; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4[e], xv[q][e], acc[q], 0, 0, 0);
+                    for (int q = 0; q < QPW; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4[e], xv[q][e], acc[q], 0, 0, 0);
+            }
         }
-    }
 
-    // ---- epilogue: lane (blk, sub) owns pixel `sub` of each quad, output channels cs0+4*blk .. +3
-    const int oc = cs0 + blk * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+        // ---- epilogue: lane (blk, sub) owns pixel `sub` of each quad, output channels cs0+4*blk .. +3
+        const int oy0 = ty * TH;
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
-        const int quad = wave * QPW + q;
-        const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
-        if (oy >= Ho || ox >= Wo) continue;
-        f32x4 v = acc[q] + bv;
-        f32x4 r;
+        for (int q = 0; q < QPW; ++q) {
+            const int quad = wave * QPW + q;
+            const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
+            if (oy >= Ho || ox >= Wo) continue;
+            f32x4 v = acc[q] + bv;
+            f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+            for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+            store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+        }
     }
 }
 
@@ -179,7 +194,7 @@ template <int STRIDE, int TH, int TW, int CPG>
 __global__ void __launch_bounds__(256)
 gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
                     _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act,
-                    int tiles_x) {
+                    int tiles_x, int tiles_y, int seg) {
     constexpr int c = CPG;
     constexpr int PSH = PixH<STRIDE>::value;
     constexpr int THIN = (TH - 1) * STRIDE + 3;
@@ -194,29 +209,35 @@ gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ w
     static_assert(TW % 4 == 0 && QUADS % 4 == 0, "tile must split into quads over 4 waves");
     extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PSH]
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // (a block walks `seg` tiles down a tile column, weights resident, next halo prefetched: see gconv_mfma4_kernel)
+    const int tx = blockIdx.x % tiles_x, sg = blockIdx.x / tiles_x;
+    const int ty_begin = sg * seg, ty_end = min(tiles_y, ty_begin + seg);
     const int cs0 = blockIdx.y * CS;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int ox0 = tx * TW;
+    const int ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = lane >> 2, sub = lane & 3;
 
     f16x8g stage[NLD];
-    {
-        const int cN = (tid % TPP) * 8;
+    const int cN = (tid % TPP) * 8;
+    auto fetch = [&](int ty) __attribute__((always_inline)) {
+        const int iy0 = ty * TH * STRIDE - pad_t;
+        int tl = tid;                                     // (opaque copy: the pixel coordinates below are recomputed per tile
+        asm volatile("" : "+v"(tl));                     //  instead of living in ~30 registers across the MFMA loop)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = tid / TPP + PPP * i;
+            const int p = tl / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
             f16x8g v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + (tl % TPP) * 8);
             stage[i] = v;
         }
-    }
+    };
+    fetch(ty_begin);
     f16x4g wv[WV];
     {
         const float *wrow = wgt + (long long)(cs0 + blk * 4 + sub) * 9 * c;
@@ -226,53 +247,57 @@ gconv_mfma4h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ w
             wv[i] = f16x4g{(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
         }
     }
-    {
-        const int cN = (tid % TPP) * 8;
+    const int gch = ((cs0 + blk * 4) / c) * c - cs0;
+    int qbase[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int quad = wave * QPW + q;
+        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
+        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PSH + gch;
+    }
+    const int oc = cs0 + blk * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        if (ty > ty_begin) __syncthreads();               // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid / TPP + PPP * i;
             if (p < NPIX) *reinterpret_cast<f16x8g *>(tileh + p * PSH + cN) = stage[i];
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        if (ty + 1 < ty_end) fetch(ty + 1);               // flies under this tile's MFMAs
 
-    const int gch = ((cs0 + blk * 4) / c) * c - cs0;
-    f32x4 acc[QPW];
-    int qbase[QPW];
+        f32x4 acc[QPW];
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
-        acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int quad = wave * QPW + q;
-        const int qy = quad / (TW / 4), qx = (quad % (TW / 4)) * 4 + sub;
-        qbase[q] = ((qy * STRIDE) * TWIN + qx * STRIDE) * PSH + gch;
-    }
+        for (int q = 0; q < QPW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * TWIN + (t % 3)) * PSH;
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * TWIN + (t % 3)) * PSH;
 #pragma unroll
-        for (int i0 = 0; i0 < c; i0 += 4) {
-            const f16x4g w4 = wv[(t * c + i0) / 4];
+            for (int i0 = 0; i0 < c; i0 += 4) {
+                const f16x4g w4 = wv[(t * c + i0) / 4];
 #pragma unroll
-            for (int q = 0; q < QPW; ++q) {
-                const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + qbase[q] + toff + i0);
-                acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(w4, xv, acc[q], 0, 0, 0);
+                for (int q = 0; q < QPW; ++q) {
+                    const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + qbase[q] + toff + i0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(w4, xv, acc[q], 0, 0, 0);
+                }
             }
         }
-    }
 
-    const int oc = cs0 + blk * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+        const int oy0 = ty * TH;
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
-        const int quad = wave * QPW + q;
-        const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
-        if (oy >= Ho || ox >= Wo) continue;
-        f32x4 v = acc[q] + bv;
-        f32x4 r;
+        for (int q = 0; q < QPW; ++q) {
+            const int quad = wave * QPW + q;
+            const int oy = oy0 + quad / (TW / 4), ox = ox0 + (quad % (TW / 4)) * 4 + sub;
+            if (oy >= Ho || ox >= Wo) continue;
+            f32x4 v = acc[q] + bv;
+            f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+            for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+            store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+        }
     }
 }
 
@@ -288,7 +313,8 @@ constexpr int PS16 = 68;   // LDS floats per pixel: 16 consecutive pixels x 16 B
 template <int STRIDE, int TH, int TW, class TIO>
 __global__ void __launch_bounds__(256)
 gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-               TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+               TIO *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x,
+               int tiles_y, int seg) {
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
@@ -300,29 +326,35 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
     static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
     extern __shared__ __align__(16) float tile[];   // [NPIX][PS16]
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // (a block walks `seg` tiles down a tile column, weights resident, next halo prefetched: see gconv_mfma4_kernel)
+    const int tx = blockIdx.x % tiles_x, sg = blockIdx.x / tiles_x;
+    const int ty_begin = sg * seg, ty_end = min(tiles_y, ty_begin + seg);
     const int cs0 = blockIdx.y * CS;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int ox0 = tx * TW;
+    const int ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
 
     typename Stage16<TIO>::type stage[NLD];
-    {
-        const int cN = (tid % TPP) * CPT;
+    const int cN = (tid % TPP) * CPT;
+    auto fetch = [&](int ty) __attribute__((always_inline)) {
+        const int iy0 = ty * TH * STRIDE - pad_t;
+        int tl = tid;                                     // (opaque copy: the pixel coordinates below are recomputed per tile
+        asm volatile("" : "+v"(tl));                     //  instead of living in ~30 registers across the MFMA loop)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = tid / TPP + PPP * i;
+            const int p = tl / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
             typename Stage16<TIO>::type v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+                v = *reinterpret_cast<const typename Stage16<TIO>::type *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + (tl % TPP) * CPT);
             stage[i] = v;
         }
-    }
+    };
+    fetch(ty_begin);
     // weights of group `wave`: out channel cs0 + 16 wave + j, taps 0..8, in channels 4q..4q+3
     f32x4 wv[9];
     {
@@ -330,49 +362,53 @@ gconv16_kernel(const TIO *__restrict__ in, const float *__restrict__ wgt, const 
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(wrow + t * 16);
     }
-    {
-        const int cN = (tid % TPP) * CPT;
+    int pbase[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        const int py = 2 * s + (j >> 3), px = j & 7;            // output pixel of this lane in set s
+        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16 + wave * 16 + 4 * q;
+    }
+    const int oc = cs0 + wave * 16 + 4 * q;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        if (ty > ty_begin) __syncthreads();               // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid / TPP + PPP * i;
             if (p < NPIX) stage_to_lds<TIO>(tile + p * PS16 + cN, stage[i]);
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        if (ty + 1 < ty_end) fetch(ty + 1);               // flies under this tile's MFMAs
 
-    f32x4 acc[SETS];
-    int pbase[SETS];
+        f32x4 acc[SETS];
 #pragma unroll
-    for (int s = 0; s < SETS; ++s) {
-        acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int py = 2 * s + (j >> 3), px = j & 7;            // output pixel of this lane in set s
-        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16 + wave * 16 + 4 * q;
-    }
+        for (int s = 0; s < SETS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * TWIN + (t % 3)) * PS16;
-        f32x4 xv[SETS];
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * TWIN + (t % 3)) * PS16;
+            f32x4 xv[SETS];
 #pragma unroll
-        for (int s = 0; s < SETS; ++s) xv[s] = *reinterpret_cast<const f32x4 *>(tile + pbase[s] + toff);
+            for (int s = 0; s < SETS; ++s) xv[s] = *reinterpret_cast<const f32x4 *>(tile + pbase[s] + toff);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int s = 0; s < SETS; ++s)
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], xv[s][e], acc[s], 0, 0, 0);
-    }
+                for (int s = 0; s < SETS; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], xv[s][e], acc[s], 0, 0, 0);
+        }
 
-    const int oc = cs0 + wave * 16 + 4 * q;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+        const int oy0 = ty * TH;
 #pragma unroll
-    for (int s = 0; s < SETS; ++s) {
-        const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
-        if (oy >= Ho || ox >= Wo) continue;
-        const f32x4 v = acc[s] + bv;
-        f32x4 r;
+        for (int s = 0; s < SETS; ++s) {
+            const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
+            if (oy >= Ho || ox >= Wo) continue;
+            const f32x4 v = acc[s] + bv;
+            f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+            for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+            store4<TIO>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
+        }
     }
 }
 
@@ -383,7 +419,8 @@ constexpr int PS16H = 72;  // LDS halves per pixel (144 B)
 template <int STRIDE, int TH, int TW>
 __global__ void __launch_bounds__(256)
 gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x) {
+                _Float16 *__restrict__ out, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, int act, int tiles_x,
+                int tiles_y, int seg) {
     constexpr int THIN = (TH - 1) * STRIDE + 3;
     constexpr int TWIN = (TW - 1) * STRIDE + 3;
     constexpr int NPIX = THIN * TWIN;
@@ -394,29 +431,35 @@ gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
     static_assert(TW == 8 && TH % 2 == 0, "a 16-pixel set is two rows of 8");
     extern __shared__ __align__(16) _Float16 tileh[];   // [NPIX][PS16H]
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // (a block walks `seg` tiles down a tile column, weights resident, next halo prefetched: see gconv_mfma4_kernel)
+    const int tx = blockIdx.x % tiles_x, sg = blockIdx.x / tiles_x;
+    const int ty_begin = sg * seg, ty_end = min(tiles_y, ty_begin + seg);
     const int cs0 = blockIdx.y * CS;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - pad_t, ix0 = ox0 * STRIDE - pad_l;
+    const int ox0 = tx * TW;
+    const int ix0 = ox0 * STRIDE - pad_l;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
 
     f16x8g stage[NLD];
-    {
-        const int cN = (tid % TPP) * 8;
+    const int cN = (tid % TPP) * 8;
+    auto fetch = [&](int ty) __attribute__((always_inline)) {
+        const int iy0 = ty * TH * STRIDE - pad_t;
+        int tl = tid;                                     // (opaque copy: the pixel coordinates below are recomputed per tile
+        asm volatile("" : "+v"(tl));                     //  instead of living in ~30 registers across the MFMA loop)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int p = tid / TPP + PPP * i;
+            const int p = tl / TPP + PPP * i;
             const int py = p / TWIN, px = p - py * TWIN;
             const int iy = iy0 + py, ix = ix0 + px;
             f16x8g v = {};
             if (p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + cN);
+                v = *reinterpret_cast<const f16x8g *>(in + ((long long)(b * H + iy) * W + ix) * C + cs0 + (tl % TPP) * 8);
             stage[i] = v;
         }
-    }
+    };
+    fetch(ty_begin);
     f16x4g wv[9];
     {
         const float *wrow = wgt + (long long)(cs0 + wave * 16 + j) * 9 * 16 + 4 * q;
@@ -426,46 +469,50 @@ gconv16h_kernel(const _Float16 *__restrict__ in, const float *__restrict__ wgt, 
             wv[t] = f16x4g{(_Float16)w[0], (_Float16)w[1], (_Float16)w[2], (_Float16)w[3]};
         }
     }
-    {
-        const int cN = (tid % TPP) * 8;
+    int pbase[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        const int py = 2 * s + (j >> 3), px = j & 7;
+        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16H + wave * 16 + 4 * q;
+    }
+    const int oc = cs0 + wave * 16 + 4 * q;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        if (ty > ty_begin) __syncthreads();               // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid / TPP + PPP * i;
             if (p < NPIX) *reinterpret_cast<f16x8g *>(tileh + p * PS16H + cN) = stage[i];
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        if (ty + 1 < ty_end) fetch(ty + 1);               // flies under this tile's MFMAs
 
-    f32x4 acc[SETS];
-    int pbase[SETS];
+        f32x4 acc[SETS];
 #pragma unroll
-    for (int s = 0; s < SETS; ++s) {
-        acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int py = 2 * s + (j >> 3), px = j & 7;
-        pbase[s] = ((py * STRIDE) * TWIN + px * STRIDE) * PS16H + wave * 16 + 4 * q;
-    }
+        for (int s = 0; s < SETS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * TWIN + (t % 3)) * PS16H;
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * TWIN + (t % 3)) * PS16H;
+#pragma unroll
+            for (int s = 0; s < SETS; ++s) {
+                const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + pbase[s] + toff);
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x16f16(wv[t], xv, acc[s], 0, 0, 0);
+            }
+        }
+
+        const int oy0 = ty * TH;
 #pragma unroll
         for (int s = 0; s < SETS; ++s) {
-            const f16x4g xv = *reinterpret_cast<const f16x4g *>(tileh + pbase[s] + toff);
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x16f16(wv[t], xv, acc[s], 0, 0, 0);
+            const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
+            if (oy >= Ho || ox >= Wo) continue;
+            const f32x4 v = acc[s] + bv;
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
+            store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
         }
-    }
-
-    const int oc = cs0 + wave * 16 + 4 * q;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + oc);
-#pragma unroll
-    for (int s = 0; s < SETS; ++s) {
-        const int oy = oy0 + 2 * s + (j >> 3), ox = ox0 + (j & 7);
-        if (oy >= Ho || ox >= Wo) continue;
-        const f32x4 v = acc[s] + bv;
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = ml_apply_act(v[e], act);
-        store4<_Float16>(out + ((long long)(b * Ho + oy) * Wo + ox) * C + oc, r);
     }
 }
 
@@ -589,6 +636,18 @@ int launch32h(const _Float16 *in, const float *wgt, const float *bias, _Float16 
     return ML_OK;
 }
 
+// Tiles a block walks down its tile column: the longest run that still leaves GCONV_BLOCKS_PER_CU blocks per CU (the blocks
+// of a CU cover each other's store / barrier phases; a launch of few long blocks would leave CUs idle at its end)
+#ifndef GCONV_BLOCKS_PER_CU
+#define GCONV_BLOCKS_PER_CU 6
+#endif
+static int column_run(int tiles_x, int tiles_y, int slabs, int B) {
+    const long long want = (long long)GCONV_BLOCKS_PER_CU * ml_resident_blocks(1);
+    int seg = tiles_y;
+    while (seg > 1 && (long long)tiles_x * ((tiles_y + seg - 1) / seg) * slabs * B < want) seg = (seg + 1) / 2;
+    return seg;
+}
+
 // kernel of a tensor type: fp32 tensors -> the fp32 MFMA forms, fp16 tensors -> the fp16 MFMA forms
 template <int STRIDE, int TH, int TW, class TIO>
 auto pick16() {
@@ -611,8 +670,9 @@ int launch16(const TIO *in, const float *wgt, const float *bias, TIO *out, int B
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C, Ho,
-                       Wo, pad_t, pad_l, act, tiles_x);
+    const int seg = column_run(tiles_x, tiles_y, C / CS, B);
+    hipLaunchKernelGGL(kern, dim3(tiles_x * ((tiles_y + seg - 1) / seg), C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H,
+                       W, C, Ho, Wo, pad_t, pad_l, act, tiles_x, tiles_y, seg);
     ML_CHECK_LAUNCH("gconv3x3");
     return ML_OK;
 }
@@ -627,8 +687,9 @@ int launch(const TIO *in, const float *wgt, const float *bias, TIO *out, int B, 
     static std::atomic<unsigned long long> lds_ok{0};      // per kernel instantiation, one bit per device
     if (int rc = ml_ensure_dynamic_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, lds_ok, "gconv3x3")) return rc;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y, C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H, W, C,
-                       Ho, Wo, pad_t, pad_l, act, tiles_x);
+    const int seg = column_run(tiles_x, tiles_y, C / CS, B);
+    hipLaunchKernelGGL(kern, dim3(tiles_x * ((tiles_y + seg - 1) / seg), C / CS, B), dim3(256), LDS_BYTES, s, in, wgt, bias, out, H,
+                       W, C, Ho, Wo, pad_t, pad_l, act, tiles_x, tiles_y, seg);
     ML_CHECK_LAUNCH("gconv3x3");
     return ML_OK;
 }

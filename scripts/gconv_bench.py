@@ -53,7 +53,8 @@ def main():
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / args.reps)
             nbytes = x.element_size() * (x.numel() + y.numel())
-            print(f"{dt} {label:30s} {1e3 * best:8.1f} us  {nbytes / best / 1e9:7.2f} TB/s (algorithmic)", flush=True)
+            chk = int(y.view(torch.int16 if dt == "f16" else torch.int32).to(torch.int64).sum().item())   # equal across builds
+            print(f"{dt} {label:30s} {1e3 * best:8.1f} us  {nbytes / best / 1e9:7.2f} TB/s (algorithmic)  checksum {chk}", flush=True)
 
 
 if __name__ == "__main__":
