@@ -269,6 +269,42 @@ def test_gconv3x3_mfma4(c, stride, filters, hw):
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype,c,stride,filters,shape", [
+    ("f32", 4, 1, 128, (8, 256, 256)),      # 8 tiles per block (32 tile rows of a column in 4 runs)
+    ("f32", 8, 2, 256, (8, 256, 256)),      # stride 2: 4 x 8 output tiles, runs of 8
+    ("f16", 16, 1, 512, (16, 80, 80)),      # half, 16 x 8 tiles: 5 tile rows in runs of 3 + 2
+    ("f16", 8, 1, 256, (16, 152, 150)),     # half, ragged map: partial tiles at the right and bottom edge, runs of 5
+])
+def test_gconv3x3_blocks_that_walk_several_tiles(dtype, c, stride, filters, shape):
+    """Round 4: in a launch that fills the chip a block walks a RUN of tiles down one tile column (weights resident, the
+    next tile's halo prefetched under the current tile's MFMAs; csrc/gconv_mfma4.hip column_run) instead of one tile.  The
+    values cannot depend on that: an image inside the batch (long runs) equals the same image run alone (one tile per
+    block at these sizes) bit for bit, and the oracle within the op tolerance (reference engine/backbone/ResNext.py:212-219)."""
+    from masklab_hip import _lib, ops, packing
+    B, H, W = shape
+    groups = filters // c
+    half = dtype == "f16"
+    x = rnd(B, H, W, filters)
+    if half:
+        x = x.astype(np.float16)
+    k = rnd(3, 3, filters, c, scale=1.0 / np.sqrt(9 * c))
+    b = rnd(filters)
+    wg, bd = dev(packing.pack_grouped_mfma4(k, groups)), dev(b)
+    xd = dev(x)
+    full = ops.gconv3x3(xd, wg, bd, c, stride=stride, act=_lib.ACT_RELU)
+    for i in (0, B - 1):
+        alone = ops.gconv3x3(xd[i:i + 1].contiguous(), wg, bd, c, stride=stride, act=_lib.ACT_RELU)
+        assert torch.equal(full[i:i + 1], alone), i
+    kk = k.astype(np.float16).astype(np.float64) if half else k          # the half kernels round the weights to half
+    ref = T.relu(O.grouped_conv_fast(x[B - 1:].astype(np.float64), kk, groups, c, stride) + b)
+    got = host(full[B - 1:]).astype(np.float64)
+    assert got.shape == ref.shape
+    if half:
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+    else:
+        np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
 def test_conv2d_transpose2x2(conv_math):
     from masklab_hip import _lib, packing
     x = rnd(5, 14, 14, 128)
