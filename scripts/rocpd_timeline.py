@@ -46,6 +46,20 @@ def main():
     for st in streams:
         iv = [(s, e) for s, e, x, _ in win if x == st]
         lines.append(f"| {st} | {len(iv) / 2:.0f} | {union_length(iv) / 2e6:.3f} |")
+    # the longest stretches with NO kernel running, and what ran before / after them
+    merged = []
+    for s_, e_, _, n_ in sorted(win):
+        if merged and s_ <= merged[-1][1]:
+            if e_ > merged[-1][1]:
+                merged[-1][1], merged[-1][3] = e_, n_
+        else:
+            merged.append([s_, e_, n_, n_])
+    gaps = [(merged[i + 1][0] - merged[i][1], merged[i][3], merged[i + 1][2]) for i in range(len(merged) - 1)]
+    idle = sum(g for g, _, _ in gaps)
+    lines += ["", f"idle between kernels: {idle / 2e6:.3f} ms per step in {len(gaps) / 2:.0f} gaps; the longest:", "",
+              "| gap us | kernel before | kernel after |", "|---|---|---|"]
+    for g, a, b in sorted(gaps, reverse=True)[:16]:
+        lines.append(f"| {g / 1e3:.1f} | `{a[:70]}` | `{b[:70]}` |")
     text = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(text)
