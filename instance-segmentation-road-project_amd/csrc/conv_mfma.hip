@@ -1269,6 +1269,17 @@ static int narrow_tile_for_small_launch(const ml_conv2d_desc *descs, int n, int 
         blocks += tiles_of(d) * splits;
     }
     const long long resident = ml_resident_blocks(2);
+    // Fixed-capacity RoI batches (round 4): their live tiles are a third of the launch, known to the device only.  Cutting
+    // K to fill the chip gave the 1-image mask head 616 blocks of 128 x 128 tiles -- one per CU, three rounds, 87 us per conv
+    // and a reduce launch behind each; the same 616 blocks as 128 x 32 tiles of the WHOLE K sum sit three to a CU.  So for
+    // these launches narrow tiles come before K slices (ref_tiles = 192: choose_splits cuts nothing from there), and the
+    // narrow forms may overfill the resident slots by half (dead tiles return at once).  1 x 512^2 MobileNet graph: 1.71 ->
+    // 1.59 ms on one box.  (The same preference for ALL small launches of moderate K -- towers, FPN -- was slower: 1.59-1.61
+    // against 1.52-1.56 ms; their K slices stay.)
+    if (n_live > 0 && ref_bn == 128) {
+        if (tiles * 4 <= resident * 3 / 2) { *ref_tiles = 192; return 3; }
+        if (tiles >= 192 && tiles * 2 <= resident * 3 / 2) { *ref_tiles = tiles; return 2; }
+    }
     *ref_tiles = tiles;
     if (blocks * (ref_bn / 32) <= resident) return 3;
     if (ref_bn == 128 && blocks * 2 <= resident) return 2;
