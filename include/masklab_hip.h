@@ -49,7 +49,8 @@ enum { ML_MATH_F32 = 0, ML_MATH_F16 = 1, ML_MATH_F16S = 2, ML_MATH_F32X3 = 3 };
                                          6: ml_conv2d_launch_splits, ml_conv2d_gn_min_launch_tiles (reporting /
                                             the size rule of gn_partials asked of the library, not restated by callers)
                                          7: ml_stem7x7s2_pool_f16 / _f32 / _x3; ml_gconv3x3_f16 takes groups of 32 channels;
-                                            ML_MATH_F32X3 on the persistent 1x1 kernel (ml_conv2d_uses_pipe)          */
+                                            ML_MATH_F32X3 on the persistent 1x1 kernel (ml_conv2d_uses_pipe);
+                                            ml_mold_levels_dev_f32                                                    */
 int ml_version(void);                 /* returns ML_ABI_VERSION of the library that was built */
 const char *ml_last_error(void);      /* text of the last failure on the calling thread   */
 int ml_device_check(void);            /* ML_OK iff device 0.. current is gfx950           */
@@ -391,6 +392,12 @@ int ml_roi_crop_resize_f16(const void *fmap, const float *rows, int32_t row_stri
  * has been enqueued.  E % 4 == 0.                                                                                 */
 int ml_mold_levels_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
                        const int32_t *n_l, void *stream);
+/* The same with the level sizes read ON THE DEVICE: lmax_dev = the L per-level RoI maxima ml_mask_distribute_f32 wrote
+ * (n_l = min(max(1, lmax), cap), as the host computes them) -- no host value enters the launch, so it can be part of a
+ * captured hipGraph; dst is a capacity buffer of B * L * cap * E floats whose FRONT receives the [B, sum n_l, E] tensor
+ * (the host, once it has read lmax, takes that front as a view: no launch after the graph).  Any E.                */
+int ml_mold_levels_dev_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
+                           const int32_t *lmax_dev, void *stream);
 
 /* x += y over n floats (n % 4 == 0): the `Add` of MobileSeparableConv2D (misc.py:92,105) */
 int ml_add_f32(float *x, const float *y, int64_t n, void *stream);

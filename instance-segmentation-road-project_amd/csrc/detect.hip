@@ -949,7 +949,46 @@ __global__ void __launch_bounds__(256) mold_levels_kernel(const f32x4 *__restric
     const int j = row - A.dst_off[l];
     dst[((long long)b * A.total + row) * E4 + e] = src[((long long)b * A.L * A.cap + (long long)l * A.cap + j) * E4 + e];
 }
+// The same concatenation with the level sizes read ON THE DEVICE (the fixed-capacity forward under a hipGraph: no host value
+// may enter the launch): n_l = max(1, lmax[l]) as the host path computes them; every source slot is visited, slots past
+// its level's n_l write nothing.  dst holds B * total * E floats at its front (total = sum n_l <= L * cap).
+template <int V>
+__global__ void __launch_bounds__(256) mold_levels_dev_kernel(const float *__restrict__ src, float *__restrict__ dst, int EV, int B, int L,
+                                                               int cap, const int *__restrict__ lmax, long long work) {
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= work) return;
+    const int e = (int)(idx % EV);
+    long long r = idx / EV;
+    const int j = (int)(r % cap);
+    r /= cap;
+    const int l = (int)(r % L), b = (int)(r / L);
+    int off = 0, total = 0, n_mine = 0;
+    for (int k = 0; k < L; ++k) {                     // (L <= 8 uniform loads)
+        const int n = min(max(lmax[k], 1), cap);
+        if (k == l) { off = total; n_mine = n; }
+        total += n;
+    }
+    if (j >= n_mine) return;
+    reinterpret_cast<vec *>(dst)[((long long)b * total + off + j) * EV + e] =
+        reinterpret_cast<const vec *>(src)[(((long long)b * L + l) * cap + j) * EV + e];
+}
 }  // namespace
+
+extern "C" int ml_mold_levels_dev_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
+                                      const int32_t *lmax_dev, void *stream) {
+    ML_REQUIRE(src && dst && lmax_dev && B > 0 && L >= 1 && L <= 8 && cap > 0 && E > 0, "mold_levels_dev: bad arguments (1..8 levels)");
+    const bool v4 = E % 4 == 0 && ml_aligned16(src) && ml_aligned16(dst);
+    const long long EV = v4 ? E / 4 : E;
+    ML_REQUIRE(EV < (1ll << 31), "mold_levels_dev: rows too long");
+    const long long work = (long long)B * L * cap * EV;
+    ML_REQUIRE((work + 255) / 256 < (1ll << 31), "mold_levels_dev: too many elements");
+    const dim3 grid((unsigned)((work + 255) / 256));
+    if (v4) hipLaunchKernelGGL(mold_levels_dev_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (int)EV, B, L, cap, lmax_dev, work);
+    else hipLaunchKernelGGL(mold_levels_dev_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (int)EV, B, L, cap, lmax_dev, work);
+    ML_CHECK_LAUNCH("mold_levels_dev");
+    return ML_OK;
+}
 
 extern "C" int ml_mold_levels_f32(const float *src, float *dst, int32_t B, int32_t L, int32_t cap, int64_t E,
                                   const int32_t *n_l, void *stream) {

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ml_mask_distribute_i32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ml_roi_crop_resize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp] + [_i32] * 10 + [_f32, _f32, _i32, _i32, _vp, _vp]),
     "ml_mold_levels_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, C.POINTER(C.c_int32), _vp]),
+    "ml_mold_levels_dev_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "ml_add_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ml_fill_f32": (C.c_int, [_vp, _f32, _i64, _vp]),
     "ml_resize_image_ac": (C.c_int, [_vp, _i32, _vp, _vp, _f32] + [_i32] * 6 + [_vp]),

@@ -789,6 +789,31 @@ def mold_levels(src, n_l, cap):
     return out
 
 
+def mold_levels_dev(src, lmax, cap):
+    """ml_mold_levels_dev_f32: the same concatenation with the level sizes read on the DEVICE (`lmax`: int32 [L], the
+    per-level RoI maxima) -- part of the captured forward.  -> a capacity buffer shaped like `src` whose flat FRONT holds the
+    [B, sum n_l, ...] tensor; `molded_front(buf, n_l)` takes it as a view once the host knows n_l."""
+    lib = _lib.load()
+    _require_dev(src, "src")
+    _require_dev(lmax, "lmax")
+    if src.dtype != torch.float32 or lmax.dtype != torch.int32:
+        raise RuntimeError("mold_levels_dev: float32 tensor and int32 level maxima expected")
+    B, L = src.shape[0], int(lmax.numel())
+    if src.shape[1] != L * cap:
+        raise ValueError(f"mold_levels_dev: {src.shape[1]} rows per image, expected {L} x {cap}")
+    E = int(np.prod(src.shape[2:]))
+    out = torch.empty_like(src)
+    _lib.check(lib.ml_mold_levels_dev_f32(_ptr(src), _ptr(out), B, L, int(cap), E, _ptr(lmax), _stream()), "ml_mold_levels_dev_f32")
+    return out
+
+
+def molded_front(buf, n_l):
+    """The [B, sum(n_l), ...] tensor at the front of a mold_levels_dev() buffer (a view: no launch)."""
+    B, total = buf.shape[0], int(sum(n_l))
+    E = int(np.prod(buf.shape[2:]))
+    return buf.view(-1)[:B * total * E].view((B, total) + tuple(buf.shape[2:]))
+
+
 def add_(x, y):
     """x += y (same shape)."""
     lib = _lib.load()

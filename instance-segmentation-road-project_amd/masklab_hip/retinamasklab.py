@@ -365,7 +365,8 @@ class InferenceModel(K.Layer):
     def capacity_bytes(self, batch):
         """Estimate of what ONE fixed-capacity stage 2 holds: per RoI level the crops and every tower / deconv
         intermediate ([B*cap, ch, cw, C] each: under graph capture none of them is recycled), plus masks_cap
-        [B, L*cap, 2ch, 2cw, classes] fp32 and the split-K workspace (per stream)."""
+        [B, L*cap, 2ch, 2cw, classes] fp32 twice (at capacity, and the buffer its molded form is the front of) and the
+        split-K workspace (per stream)."""
         from . import ops
         ins = self.configuration.instance
         pra, mask = self.instance_networks[2], self.instance_networks[3]
@@ -376,7 +377,7 @@ class InferenceModel(K.Layer):
         slots = int(batch) * cap
         per_level = slots * ch * cw * mask.num_features * es * (2 + mask.num_depth)
         masks = slots * L * 4 * ch * cw * mask.num_classes * 4
-        return L * per_level + masks + 2 * int(ops._lib.load().ml_conv2d_workspace_bytes())
+        return L * per_level + 2 * masks + 2 * int(ops._lib.load().ml_conv2d_workspace_bytes())   # (masks: at capacity + molded)
 
     def _capacity_wanted(self, images):
         mode = getattr(self, "device_counts", "auto")
@@ -398,6 +399,7 @@ class InferenceModel(K.Layer):
         """RoI crops + mask head with every level at capacity (reference engine/layers/instance.py:115-134,211-233 +
         MoldBatch misc.py:231-286): kernels skip the RoI slots past the level maxima they read on the device.
         -> the forward's RAW result: fixed-shape tensors + `lmax` (what `_mold` needs the host to read)."""
+        from . import ops
         _, _, pyramid_roi_align, mask_subnet = self.instance_networks
         roi_fmaps, boxes_cap, lives = pyramid_roi_align.crop_capacity(
             st["roi_features"], st["proposed"], st["image_hw"], st["slots"], st["lcounts"], st["lmax"])
@@ -405,15 +407,21 @@ class InferenceModel(K.Layer):
         self.last_detections = dict(proposed=st["proposed"], counts=st["counts"], kept=st["kept"], boxes=st["boxes"],
                                     payload=st["payload"], level_counts=st["lcounts"], level_max=st["lmax"])
         self._join_side(st)
+        # MoldBatch + Concatenate(axis=1) at the front of two capacity buffers, sized on the device from `lmax`: part of the
+        # captured forward, so that nothing is launched after it (round 4: the two molding launches behind the host's read
+        # left the GPU idle for their launch latencies -- 0.25 ms of gaps per forward under a kernel trace at 1 x 512^2)
+        cap = int(st["proposed"].shape[1])
         return dict(cls_pred=st["cls_pred"], loc_pred=st["loc_pred"], boxes_cap=boxes_cap, masks_cap=masks_cap,
-                    lmax=st["lmax"], cap=int(st["proposed"].shape[1]), seg_pred=st.get("seg_pred"))
+                    boxes_molded=ops.mold_levels_dev(boxes_cap, st["lmax"], cap),
+                    masks_molded=ops.mold_levels_dev(masks_cap, st["lmax"], cap),
+                    lmax=st["lmax"], cap=cap, seg_pred=st.get("seg_pred"))
 
     def _mold(self, raw):
         """The ONE host read of the forward (the per-level RoI maxima, L ints) and the molded outputs it sizes."""
         from . import ops
-        n_l = [max(1, int(v)) for v in raw["lmax"].tolist()]
-        outputs = [raw["cls_pred"], raw["loc_pred"], ops.mold_levels(raw["boxes_cap"], n_l, raw["cap"]),
-                   ops.mold_levels(raw["masks_cap"], n_l, raw["cap"])]
+        n_l = [min(max(1, int(v)), raw["cap"]) for v in raw["lmax"].tolist()]
+        outputs = [raw["cls_pred"], raw["loc_pred"], ops.molded_front(raw["boxes_molded"], n_l),
+                   ops.molded_front(raw["masks_molded"], n_l)]
         if self.semantic_networks is not None:
             outputs.append(raw["seg_pred"])
         return outputs

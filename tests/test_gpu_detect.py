@@ -220,3 +220,24 @@ def test_prior_layer_matches_oracle():
     ref = _anchors(128, 384)
     assert out.shape == (2,) + ref.shape and out.dtype == torch.int32
     np.testing.assert_array_equal(host(out[1].contiguous()), ref)
+
+
+@pytest.mark.parametrize("B,L,cap,tail,lmax", [(1, 3, 100, (28, 28, 5), [37, 0, 12]), (2, 3, 10, (6,), [10, 1, 3]),
+                                               (3, 4, 7, (4, 4, 3), [0, 0, 0, 0]), (2, 2, 5, (6,), [9, 2])])
+def test_mold_levels_on_the_device_equals_the_host_sized_concatenation(B, L, cap, tail, lmax):
+    """ml_mold_levels_dev_f32 (round 4): MoldBatch + Concatenate(axis=1) of a fixed-capacity stage 2 with the level sizes
+    read on the DEVICE -- n_l = min(max(1, lmax), cap), the host rule (reference engine/layers/misc.py:231-286,
+    instance.py:222-225) -- so that the launch can be part of the captured forward.  The front of its capacity buffer, taken
+    as a view once the host knows n_l, equals the slicing the reference's layers do; both row lengths (E % 4 == 0: 16-byte
+    copies; E = 6: the box rows)."""
+    from masklab_hip import ops
+    rng = np.random.default_rng(3)
+    src = rng.normal(size=(B, L * cap) + tail).astype(np.float32)
+    n_l = [min(max(1, v), cap) for v in lmax]
+    want = np.concatenate([src[:, l * cap:l * cap + n] for l, n in enumerate(n_l)], axis=1)
+    buf = ops.mold_levels_dev(dev(src), dev(np.asarray(lmax, np.int32)), cap)
+    got = ops.molded_front(buf, n_l)
+    assert got.is_contiguous() and tuple(got.shape) == want.shape
+    np.testing.assert_array_equal(host(got), want)
+    if int(np.prod(tail)) % 4 == 0:            # the host-sized launch (kept in the ABI) gives the same tensor
+        np.testing.assert_array_equal(host(ops.mold_levels(dev(src), n_l, cap)), want)
